@@ -1,0 +1,92 @@
+"""Shared helpers for the parity tests (no reference code, no GPU needed)."""
+import os
+
+import numpy as np
+import torch
+
+from simpb_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def golden_params(g):
+    """Procedural parameters for the reference state_dict recorded in a head golden."""
+    params = {}
+    for key, shp in zip(g["state_keys"].tolist(), g["state_shapes"].tolist()):
+        shape = tuple(int(s) for s in shp.split(",")) if shp else ()
+        if key.endswith("fix_scale"):
+            val = np.asarray([[0, 0, 0], [0.45, 0, 0], [-0.45, 0, 0], [0, 0.45, 0], [0, -0.45, 0],
+                              [0, 0, 0.45], [0, 0, -0.45]], np.float32)  # config :224-232
+        else:
+            val = synth.procedural_tensor(key, shape)
+        params[key] = torch.as_tensor(np.asarray(val))
+    return params
+
+
+def spec_of(g):
+    s = {k[5:]: g[k] for k in g.files if k.startswith("spec_")}
+    jump = tuple(s["jump"].tolist()) if s["jump"].ndim else None
+    if jump is not None:
+        jump = (int(jump[0]), int(jump[1]), float(jump[2]))
+    return dict(image_wh=tuple(int(v) for v in s["image_wh"]), num_anchor=int(s["num_anchor"]),
+                num_temp=int(s["num_temp"]), num_output=int(s["num_output"]), bs=int(s["bs"]),
+                frames=int(s["frames"]), jump=jump, trace_frames=tuple(int(v) for v in s["trace_frames"]))
+
+
+def compare_trace(got, g, prefix, rtol=2e-4, atol=2e-4, skip=()):
+    """Compare a synth.Trace against the golden arrays under `prefix`; returns the list of names
+    checked. Float records use |a-b| <= atol + rtol*max|b| (sketches mix a row, so the scale of
+    the whole record is the right yardstick); integer records must match exactly."""
+    names = [k[len(prefix):] for k in g.files if k.startswith(prefix)]
+    assert names, prefix
+    missing = [n for n in names if n not in got.items and not any(n.startswith(s) for s in skip)]
+    assert not missing, f"trace records missing: {missing[:5]}"
+    bad = []
+    for n in names:
+        if any(n.startswith(s) for s in skip):
+            continue
+        a, b = np.asarray(got.items[n]), g[prefix + n]
+        if a.shape != b.shape:
+            bad.append((n, "shape", a.shape, b.shape))
+            continue
+        if np.issubdtype(b.dtype, np.floating):
+            tol = atol + rtol * float(np.abs(b).max() if b.size else 0.0)
+            err = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) if b.size else 0.0
+            if not err <= tol:
+                bad.append((n, "err", err, tol))
+        elif not np.array_equal(a.astype(np.int64), b.astype(np.int64)):
+            bad.append((n, "int mismatch", int((a != b).sum()), a.size))
+    assert not bad, f"{len(bad)} of {len(names)} trace records differ, first: {bad[:6]}"
+    return names
+
+
+def compare_result(res, g, prefix, box_tol=1e-3, score_tol=1e-3):
+    """One sample's decode_with2d dict against the golden: SURVEY.md §7 'compare sets with
+    tolerance' — rows are matched by position after the reference's own score sort; ties in
+    top-k would show up as a row mismatch and are reported with the score gap."""
+    def G(k):
+        return g[prefix + k]
+
+    for k, tol in (("boxes_3d", box_tol), ("scores_3d", score_tol), ("cls_scores", score_tol),
+                   ("boxes_2d", box_tol * 100), ("scores_2d", score_tol)):
+        a, b = np.asarray(res[k].detach().cpu() if torch.is_tensor(res[k]) else res[k], np.float64), G(k).astype(np.float64)
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        if k == "boxes_3d":  # yaw wraps
+            d = np.abs(a - b)
+            d[:, 6] = np.minimum(d[:, 6], 2 * np.pi - d[:, 6])
+            err = d.max()
+        else:
+            err = np.abs(a - b).max() if b.size else 0.0
+        assert err <= tol, (k, err, tol)
+    for k in ("labels_3d", "labels_2d", "camidx_2d", "instance_ids"):
+        a = np.asarray(res[k].detach().cpu() if torch.is_tensor(res[k]) else res[k]).astype(np.int64)
+        assert np.array_equal(a, G(k).astype(np.int64)), k
+    t = res["trans_matrix"]
+    nz = torch.nonzero(t.detach().cpu()).numpy().astype(np.int64)
+    assert tuple(t.shape) == tuple(G("trans_shape").tolist())
+    assert np.array_equal(nz, G("trans_nz").astype(np.int64))
+    assert np.array_equal(np.asarray(res["query_groups"], np.int64), G("query_groups").astype(np.int64))

@@ -96,6 +96,10 @@ def run_head(ns, cfg, spec, fname):
     torch.manual_seed(0)
     head = build_ref_head(ns, cfg, spec)
     data = {"spec_" + k: np.asarray(v if v is not None else -1) for k, v in spec.items()}
+    sd = head.state_dict()
+    data["state_keys"] = np.asarray(list(sd.keys()))
+    data["state_shapes"] = np.asarray([",".join(map(str, v.shape)) for v in sd.values()])
+    data["operation_order"] = np.asarray(head.operation_order)
     with torch.no_grad():
         for f in range(spec["frames"]):
             trace = synth.Trace()
