@@ -1,0 +1,40 @@
+"""ctypes binding of include/simpb_hip.h. The library is mandatory: there is no CPU or PyTorch
+fallback behind these entry points, and a missing .so is an error, not a silent downgrade."""
+import ctypes
+import os
+
+from .build import LIB
+
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+
+SIGNATURES = {
+    "simpb_abi_version": ([], _I),
+    "simpb_deformable_aggregation_forward": ([_P] * 6 + [_I] * 8 + [_P], _I),
+    "simpb_ms_deform_attn_grouped_forward": ([_P] * 7 + [_I] * 8 + [_P], _I),
+}
+
+ERRORS = {1: "SIMPB_EINVAL (bad pointer/size/layout)", 2: "SIMPB_ELAUNCH (kernel launch failed)"}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError(
+                f"{LIB} is missing: build it with `python -m simpb_amd.build` (hipcc --offload-arch=gfx950). "
+                "simpb_amd has no fallback path for its HIP kernels.")
+        handle = ctypes.CDLL(LIB)
+        for name, (argtypes, restype) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if include/simpb_hip.h and the .so disagree
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(status, status)}")

@@ -1,0 +1,166 @@
+"""Operator layer: same names and argument meaning as the reference's
+projects/mmdet3d_plugin/ops/__init__.py and ops/deformable_aggregation.py, bound to the C-ABI HIP
+library (include/simpb_hip.h) instead of the pybind11 CUDA extension. No CPU path exists here:
+tensors must live on the GPU and the library must be built."""
+import ctypes
+
+import torch
+from torch.autograd.function import Function
+
+from .. import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("simpb_amd operators run on the GPU only (got a CPU tensor); "
+                               "there is no CPU fallback")
+
+
+_layout_ok = {}
+
+
+def _check_layout(spatial_shape, scale_start_index, num_feat):
+    """Host-side bounds check of the (H, W, start) table the kernel will index with. Costs one
+    device->host copy the first time a given table tensor is seen; the head reuses its tables."""
+    key = (spatial_shape.data_ptr(), scale_start_index.data_ptr(), spatial_shape._version,
+           scale_start_index._version, num_feat)
+    if key in _layout_ok:
+        return
+    ss = spatial_shape.detach().cpu().long()
+    st = scale_start_index.detach().cpu().long()
+    if bool((ss <= 0).any()) or bool((st < 0).any()) or int((st + ss[..., 0] * ss[..., 1]).max()) > num_feat:
+        raise ValueError("spatial_shape/scale_start_index address tokens outside mc_ms_feat")
+    if len(_layout_ok) > 64:
+        _layout_ok.clear()
+    _layout_ok[key] = True
+
+
+class DeformableAggregationFunction(Function):
+    """ops/deformable_aggregation.py:7-37 (forward). The backward of the reference (:39-75) is
+    training-only and not part of this path yet."""
+
+    @staticmethod
+    def forward(ctx, mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights):
+        _require_gpu(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights)
+        mc_ms_feat = mc_ms_feat.contiguous().float()
+        spatial_shape = spatial_shape.contiguous().int()
+        scale_start_index = scale_start_index.contiguous().int()
+        sampling_location = sampling_location.contiguous().float()
+        weights = weights.contiguous().float()
+        bs, num_feat, num_embeds = mc_ms_feat.shape
+        num_cams, num_scale = spatial_shape.shape[:2]
+        _, num_anchors, num_pts = sampling_location.shape[:3]
+        num_groups = weights.shape[5]
+        # the kernel indexes with these shapes; refuse anything inconsistent before launching
+        if tuple(spatial_shape.shape) != (num_cams, num_scale, 2) or tuple(scale_start_index.shape) != (num_cams, num_scale):
+            raise ValueError("spatial_shape must be [cam, lvl, 2] and scale_start_index [cam, lvl]")
+        if tuple(sampling_location.shape) != (bs, num_anchors, num_pts, num_cams, 2):
+            raise ValueError(f"sampling_location must be [bs, anchor, pts, cam, 2], got {tuple(sampling_location.shape)}")
+        if tuple(weights.shape) != (bs, num_anchors, num_pts, num_cams, num_scale, num_groups):
+            raise ValueError(f"weights must be [bs, anchor, pts, cam, lvl, group], got {tuple(weights.shape)}")
+        if num_embeds % num_groups != 0:
+            raise ValueError("num_embeds must be divisible by num_groups")
+        _check_layout(spatial_shape, scale_start_index, num_feat)
+        output = torch.empty(bs, num_anchors, num_embeds, device=mc_ms_feat.device, dtype=torch.float32)
+        status = _lib.lib().simpb_deformable_aggregation_forward(
+            _ptr(output), _ptr(mc_ms_feat), _ptr(spatial_shape), _ptr(scale_start_index), _ptr(sampling_location),
+            _ptr(weights), bs, num_cams, num_feat, num_embeds, num_scale, num_anchors, num_pts, num_groups, _stream())
+        _lib.check(status, "simpb_deformable_aggregation_forward")
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        raise NotImplementedError("deformable_aggregation backward is not part of the inference hot path")
+
+
+def deformable_aggregation_function(feature_maps, spatial_shape, scale_start_index, sampling_location, weights):
+    """ops/__init__.py:6-19."""
+    return DeformableAggregationFunction.apply(feature_maps, spatial_shape, scale_start_index, sampling_location, weights)
+
+
+def feature_maps_format(feature_maps, inverse=False):
+    """ops/__init__.py:22-92. Forward direction: list of [bs, cam, C, H, W] ->
+    [col_feats [bs, sum(cam*H*W), C], spatial_shape i64[cam, lvl, 2], scale_start_index i64[cam, lvl]].
+    Maps that are already channels_last in memory make the permute a cheap strided copy."""
+    if inverse:
+        col_feats, spatial_shape, scale_start_index = feature_maps
+        num_cams, num_levels = spatial_shape.shape[:2]
+        shapes = spatial_shape[0].tolist()
+        if not bool((spatial_shape == spatial_shape[:1]).all()):
+            raise NotImplementedError("inverse format with per-camera shapes")
+        bs = col_feats.shape[0]
+        per_cam = col_feats.reshape(bs, num_cams, -1, col_feats.shape[-1])
+        out, start = [], 0
+        for h, w in shapes:
+            out.append(per_cam[:, :, start:start + h * w].reshape(bs, num_cams, h, w, -1).permute(0, 1, 4, 2, 3))
+            start += h * w
+        return [out]
+
+    if isinstance(feature_maps[0], (list, tuple)):
+        formated = [feature_maps_format(x) for x in feature_maps]
+        return [torch.cat([x[0] for x in formated], dim=1), torch.cat([x[1] for x in formated], dim=0),
+                torch.cat([x[2] for x in formated], dim=0)]
+
+    bs, num_cams = feature_maps[0].shape[:2]
+    shapes = [tuple(f.shape[-2:]) for f in feature_maps]
+    col = torch.cat([f.reshape(bs, num_cams, f.shape[2], -1) for f in feature_maps], dim=-1)
+    col = col.permute(0, 1, 3, 2).flatten(1, 2)
+    spatial_shape = torch.tensor([shapes] * num_cams, dtype=torch.int64, device=col.device)
+    sizes = [h * w for h, w in shapes] * num_cams
+    starts = [0]
+    for s in sizes[:-1]:
+        starts.append(starts[-1] + s)
+    scale_start_index = torch.tensor(starts, dtype=torch.int64, device=col.device).reshape(num_cams, -1)
+    return [col, spatial_shape, scale_start_index]
+
+
+def query_cam_from_groups(query_groups, num_query, device):
+    """[(start, end)] * num_cams (allocation.py:99) -> i32[num_query] camera id per query slot."""
+    cam = torch.zeros(num_query, dtype=torch.int32)
+    for i, (s, e) in enumerate(query_groups):
+        cam[s:e] = i
+    return cam.to(device)
+
+
+def ms_deform_attn_grouped(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, query_cam):
+    """One launch for what group_attn.py:227-235 does with a Python loop over cameras and
+    MultiScaleDeformableAttnFunction.apply. value [bs, cam, Nv, heads, ch]; sampling_locations
+    [bs, Nq, heads, lvl, pts, 2]; attention_weights [bs, Nq, heads, lvl, pts]; query_cam i32[Nq]
+    -> [bs, Nq, heads*ch]."""
+    _require_gpu(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, query_cam)
+    value = value.contiguous().float()
+    spatial_shapes = spatial_shapes.contiguous().long()
+    level_start_index = level_start_index.contiguous().long()
+    sampling_locations = sampling_locations.contiguous().float()
+    attention_weights = attention_weights.contiguous().float()
+    query_cam = query_cam.contiguous().int()
+    bs, num_cams, num_value, heads, ch = value.shape
+    _, nq, _, lvls, pts, _ = sampling_locations.shape
+    if tuple(sampling_locations.shape) != (bs, nq, heads, lvls, pts, 2):
+        raise ValueError(f"sampling_locations must be [bs, Nq, heads, lvl, pts, 2], got {tuple(sampling_locations.shape)}")
+    if tuple(attention_weights.shape) != (bs, nq, heads, lvls, pts):
+        raise ValueError(f"attention_weights must be [bs, Nq, heads, lvl, pts], got {tuple(attention_weights.shape)}")
+    if tuple(spatial_shapes.shape) != (lvls, 2) or tuple(level_start_index.shape) != (lvls,):
+        raise ValueError("spatial_shapes must be [lvl, 2] and level_start_index [lvl]")
+    if query_cam.numel() != nq:
+        raise ValueError("query_cam must have one entry per query slot")
+    if ch % 4 != 0:
+        raise ValueError("channels per head must be a multiple of 4")
+    _check_layout(spatial_shapes[None], level_start_index[None], num_value)
+    output = torch.empty(bs, nq, heads * ch, device=value.device, dtype=torch.float32)
+    if nq == 0:
+        return output
+    status = _lib.lib().simpb_ms_deform_attn_grouped_forward(
+        _ptr(output), _ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_locations),
+        _ptr(attention_weights), _ptr(query_cam), bs, num_cams, num_value, heads, ch, lvls, pts, nq, _stream())
+    _lib.check(status, "simpb_ms_deform_attn_grouped_forward")
+    return output

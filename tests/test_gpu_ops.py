@@ -1,0 +1,125 @@
+"""GPU: the two hand-written samplers, called through the C-ABI, against the oracle on the same
+seeded inputs and against the golden vectors. Tolerances are stated per test; both sides are fp32
+and differ only in summation order."""
+import numpy as np
+import pytest
+import torch
+
+from simpb_amd import synth
+from tests.helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from simpb_amd.plugin import ops
+    return ops
+
+
+def _oracle():
+    from oracle import simpb_ref
+    return simpb_ref
+
+
+def test_library_loaded():
+    from simpb_amd import _lib
+    assert _lib.lib().simpb_abi_version() == 1
+
+
+def test_daf_golden_fallback_case():
+    from tests.test_oracle_golden import daf_case
+    g = load_golden("ops.npz")
+    col, ss, ssi, loc, w = daf_case(g)
+    out = _ops().deformable_aggregation_function(col.cuda(), ss.cuda(), ssi.cuda(), loc.cuda(), w.cuda())
+    assert np.abs(out.cpu().numpy() - g["daf.out_fallback"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [
+    dict(bs=2, A=37, P=13, K=6, L=4, G=8, C=256, maps=[(16, 44), (8, 22), (4, 11), (2, 6)]),   # fast path, shipped C/G
+    dict(bs=1, A=5, P=3, K=2, L=2, G=4, C=64, maps=[(5, 7), (3, 2)]),                       # fast path, partial wave
+    dict(bs=2, A=9, P=4, K=3, L=5, G=3, C=30, maps=[(6, 5), (3, 3), (2, 2), (1, 1), (1, 3)]),  # generic path, 5 levels
+    dict(bs=1, A=4, P=25, K=6, L=1, G=8, C=256, maps=[(8, 8)]),                              # P*K > 128 -> generic
+])
+def test_daf_random_vs_oracle(shape):
+    """Locations drawn from [-0.2, 1.2] so the (0,1) gate, the border taps and the zero padding
+    are all exercised; plus exact 0 and 1."""
+    R = _oracle()
+    s = shape
+    rs = np.random.RandomState(7)
+    maps = [torch.from_numpy(rs.standard_normal((s["bs"], s["K"], s["C"], h, w)).astype(np.float32)) for h, w in s["maps"]]
+    col, ss, ssi = R.feature_maps_format(maps)
+    loc = torch.from_numpy(rs.uniform(-0.2, 1.2, (s["bs"], s["A"], s["P"], s["K"], 2)).astype(np.float32))
+    loc[0, 0, 0, 0, 0] = 0.0
+    loc[0, 1, 0, 0, 1] = 1.0
+    loc[0, 2, 0, 0] = torch.tensor([1e-6, 1 - 1e-6])
+    w = torch.from_numpy(rs.uniform(0, 1, (s["bs"], s["A"], s["P"], s["K"], s["L"], s["G"])).astype(np.float32))
+    want = R.deformable_aggregation(col, ss.int(), ssi.int(), loc, w)
+    got = _ops().deformable_aggregation_function(col.cuda(), ss.cuda(), ssi.cuda(), loc.cuda(), w.cuda()).cpu()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * max(scale, 1.0)
+
+
+def test_daf_full_size_properties():
+    """BASELINE.json config #2 shapes (89 760 tokens x 256): linearity in the weights and the
+    constant-map identity (out = sum of valid weights), which need no oracle run at this size,
+    then the oracle itself on the same input."""
+    R = _oracle()
+    ops = _ops()
+    fm = R.feature_maps_format(synth.feature_maps_nchw(1, 0))
+    col, ss, ssi = fm[0].cuda(), fm[1].cuda(), fm[2].cuda()
+    rs = np.random.RandomState(3)
+    loc = torch.from_numpy(rs.uniform(-0.5, 1.5, (1, 900, 13, 6, 2)).astype(np.float32)).cuda()
+    w1 = torch.from_numpy(rs.uniform(0, 1, (1, 900, 13, 6, 4, 8)).astype(np.float32)).cuda()
+    w2 = torch.from_numpy(rs.uniform(0, 1, (1, 900, 13, 6, 4, 8)).astype(np.float32)).cuda()
+    o1 = ops.deformable_aggregation_function(col, ss, ssi, loc, w1)
+    o2 = ops.deformable_aggregation_function(col, ss, ssi, loc, w2)
+    o12 = ops.deformable_aggregation_function(col, ss, ssi, loc, w1 + 2 * w2)
+    assert float((o12 - (o1 + 2 * o2)).abs().max()) < 2e-3
+    assert torch.equal(o1, ops.deformable_aggregation_function(col, ss, ssi, loc, w1))  # deterministic
+    ones = torch.ones_like(col)
+    keep = ((loc > 0) & (loc < 1)).all(-1)
+    oc = ops.deformable_aggregation_function(ones, ss, ssi, loc, w1)
+    upper = (w1 * keep[..., None, None]).sum(dim=(2, 3, 4)).repeat_interleave(32, dim=-1)
+    assert bool((oc <= upper + 1e-3).all())  # border taps only remove mass
+    want = R.deformable_aggregation(fm[0], fm[1].int(), fm[2].int(), loc.cpu(), w1.cpu())
+    assert float((o1.cpu() - want).abs().max()) <= 1e-4 * max(float(want.abs().max()), 1.0)
+
+
+def _msda_inputs(bs, nq, heads, ch, shapes, pts, ncam, seed):
+    rs = np.random.RandomState(seed)
+    nv = sum(h * w for h, w in shapes)
+    value = torch.from_numpy(rs.standard_normal((bs, ncam, nv, heads, ch)).astype(np.float32))
+    loc = torch.from_numpy(rs.uniform(-0.3, 1.3, (bs, nq, heads, len(shapes), pts, 2)).astype(np.float32))
+    aw = torch.from_numpy(rs.uniform(0, 1, (bs, nq, heads, len(shapes), pts)).astype(np.float32))
+    ss = torch.tensor(shapes, dtype=torch.long)
+    lsi = torch.cat([ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]])
+    bounds = sorted(rs.choice(np.arange(nq + 1), ncam - 1).tolist())
+    groups = list(zip([0] + bounds, bounds + [nq]))
+    return value, ss, lsi, loc, aw, groups
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(bs=2, nq=53, heads=8, ch=32, shapes=[(8, 22), (4, 11), (2, 6), (1, 3)], pts=4, ncam=6),  # shipped layout
+    dict(bs=1, nq=17, heads=4, ch=8, shapes=[(5, 4), (2, 3)], pts=3, ncam=3),                    # generic points
+    dict(bs=1, nq=9, heads=16, ch=32, shapes=[(6, 6), (3, 3), (2, 2), (1, 1), (1, 2)], pts=8, ncam=2),  # 512 channels
+])
+def test_msda_grouped_vs_oracle(cfg):
+    R = _oracle()
+    value, ss, lsi, loc, aw, groups = _msda_inputs(seed=11, **cfg)
+    outs = []
+    for i, (s, e) in enumerate(groups):
+        if e > s:
+            outs.append(R.ms_deform_attn(value[:, i].contiguous(), ss, loc[:, s:e].contiguous(), aw[:, s:e].contiguous()))
+    want = torch.cat(outs, dim=1)
+    ops = _ops()
+    qcam = ops.query_cam_from_groups(groups, cfg["nq"], "cuda")
+    got = ops.ms_deform_attn_grouped(value.cuda(), ss.cuda(), lsi.cuda(), loc.cuda(), aw.cuda(), qcam).cpu()
+    assert float((got - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1.0)
+
+
+def test_ops_reject_cpu_tensors():
+    ops = _ops()
+    with pytest.raises(RuntimeError):
+        ops.deformable_aggregation_function(torch.zeros(1, 4, 8), torch.ones(1, 1, 2, dtype=torch.int32) * 2,
+                                            torch.zeros(1, 1, dtype=torch.int32), torch.zeros(1, 1, 1, 1, 2),
+                                            torch.zeros(1, 1, 1, 1, 1, 2))
