@@ -54,6 +54,50 @@ int simpb_ms_deform_attn_grouped_forward(
     int batch_size, int num_cams, int num_value, int num_heads, int channels,
     int num_levels, int num_points, int num_query, void* stream);
 
+/* Adaptive query allocation, replaces DynamicQueryAllocation.projection_allocation
+ * (models/allocation.py:27-144) in three steps; the caller reads `count` back between steps 2
+ * and 3 to size the 2D query set (the reference does the same with .tolist() at :94).
+ *
+ * Step 1 (:30-83): project the 8 box corners (size = exp(wlh) clamped to limit_*) and the centre of
+ * every anchor into every camera.
+ *   anchor         f32 [batch_size, num_anchors, 11]   x,y,z,log w,log l,log h,sin,cos,vx,vy,vz
+ *   projection_mat f32 [batch_size, num_cams, 4, 4]
+ *   flag           u8  [batch_size, num_cams, num_anchors]   0 none, 1 corner-only, 2 centre valid
+ *   sel_xy         f32 [batch_size, num_cams, num_anchors, 2] reference point in pixels
+ *   depth          f32 [batch_size, num_cams, num_anchors]    centre depth (signed) */
+int simpb_alloc_project(unsigned char* flag, float* sel_xy, float* depth, const float* anchor,
+                        const float* projection_mat, int batch_size, int num_anchors, int num_cams,
+                        float img_w, float img_h, float limit_w, float limit_l, float limit_h, void* stream);
+
+/* Step 2 (:86-123): per (batch, cam) stable compaction in ascending anchor order.
+ *   count i32 [batch_size, num_cams]; order i32 [batch_size, num_cams, num_anchors] (first count valid) */
+int simpb_alloc_compact(int* count, int* order, const unsigned char* flag, int batch_size, int num_anchors,
+                        int num_cams, void* stream);
+
+/* Step 3 (:103-142): fill the slot tables. group_start i32 [num_cams + 1] (device) are the
+ * max-over-batch prefix sums (:91-99); slots past a sample's own count are pads (q2a = -1, zeros).
+ *   ref_pts2d f32 [bs, num_query, 2] (divided by img_w, img_h); ref_depth2d f32 [bs, num_query, 1] = |depth|
+ *   q2a i32 [bs, num_query] slot -> anchor; is_center i32 [bs, num_query];
+ *   a2q i32 [bs, num_anchors, num_cams] (anchor, cam) -> slot or -1; query_cam i32 [num_query]
+ * q2a/is_center are the index form of the reference's one-hot trans_matrix / center_matrix. */
+int simpb_alloc_scatter(float* ref_pts2d, float* ref_depth2d, int* q2a, int* is_center, int* a2q, int* query_cam,
+                        const int* group_start, const int* count, const int* order, const unsigned char* flag,
+                        const float* sel_xy, const float* depth, int batch_size, int num_anchors, int num_cams,
+                        int num_query, float img_w, float img_h, void* stream);
+
+/* out[b, s, :] = src[b, q2a[b, s], :], zeros where q2a < 0: replaces
+ * torch.matmul(ref_trans_matrix, instance_feature) (models/simpb_head.py:438). channels % 4 == 0. */
+int simpb_gather_rows(float* out, const float* src, const int* q2a, int batch_size, int num_anchors,
+                      int num_query, int channels, void* stream);
+
+/* 2D -> 3D re-weighted mean, replaces ReWeight.forward's two dense matmuls
+ * (models/aggregation.py:30-35) plus the adds at :88-89:
+ *   out_q[b,a]   = q3d[b,a]   + sum_s alpha[b,s] q2d[b,s]   / clamp(sum_s alpha[b,s], 1e-5)
+ *   out_pos[b,a] = pos3d[b,a] + sum_s alpha[b,s] pos2d[b,s] / clamp(...)      s over a2q[b,a,:] >= 0 */
+int simpb_aggregate_2d_to_3d(float* out_q, float* out_pos, const float* q3d, const float* pos3d, const float* q2d,
+                             const float* pos2d, const float* alpha, const int* a2q, int batch_size,
+                             int num_anchors, int num_cams, int num_query, int channels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

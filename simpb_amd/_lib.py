@@ -9,11 +9,17 @@ _lib = None
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
+_F = ctypes.c_float
 
 SIGNATURES = {
     "simpb_abi_version": ([], _I),
     "simpb_deformable_aggregation_forward": ([_P] * 6 + [_I] * 8 + [_P], _I),
     "simpb_ms_deform_attn_grouped_forward": ([_P] * 7 + [_I] * 8 + [_P], _I),
+    "simpb_alloc_project": ([_P] * 5 + [_I] * 3 + [_F] * 5 + [_P], _I),
+    "simpb_alloc_compact": ([_P] * 3 + [_I] * 3 + [_P], _I),
+    "simpb_alloc_scatter": ([_P] * 12 + [_I] * 4 + [_F] * 2 + [_P], _I),
+    "simpb_gather_rows": ([_P] * 3 + [_I] * 4 + [_P], _I),
+    "simpb_aggregate_2d_to_3d": ([_P] * 8 + [_I] * 5 + [_P], _I),
 }
 
 ERRORS = {1: "SIMPB_EINVAL (bad pointer/size/layout)", 2: "SIMPB_ELAUNCH (kernel launch failed)"}

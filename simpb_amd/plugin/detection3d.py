@@ -1,0 +1,317 @@
+"""models/detection3d/{blocks,decoder}.py of the reference: 3D box encoder, refinement head,
+key-point generator and the box decoder. The training-only target/loss classes of that package
+are registered as inert stand-ins in training_stubs.py."""
+import torch
+import torch.nn as nn
+
+from .box3d import *  # noqa: F401,F403
+from .box3d import COS_YAW, H, L, SIN_YAW, VX, W, X, Y, Z, CNS
+from .layers import BaseModule, Linear, Scale, bias_init_with_prob, linear_relu_ln
+from .registry import BBOX_CODERS, PLUGIN_LAYERS, POSITIONAL_ENCODING
+
+__all__ = ["SparseBox3DRefinementModule", "SparseBox3DKeyPointsGenerator", "SparseBox3DEncoder", "SparseBox3DDecoder"]
+
+
+@POSITIONAL_ENCODING.register_module()
+class SparseBox3DEncoder(BaseModule):
+    """detection3d/blocks.py:23-74."""
+
+    def __init__(self, embed_dims, vel_dims=3, mode="add", output_fc=True, in_loops=1, out_loops=2):
+        super().__init__()
+        assert mode in ["add", "cat"]
+        self.embed_dims = embed_dims
+        self.vel_dims = vel_dims
+        self.mode = mode
+
+        def embedding_layer(input_dims, output_dims):
+            return nn.Sequential(*linear_relu_ln(output_dims, in_loops, out_loops, input_dims))
+
+        if not isinstance(embed_dims, (list, tuple)):
+            embed_dims = [embed_dims] * 5
+        self.pos_fc = embedding_layer(3, embed_dims[0])
+        self.size_fc = embedding_layer(3, embed_dims[1])
+        self.yaw_fc = embedding_layer(2, embed_dims[2])
+        if vel_dims > 0:
+            self.vel_fc = embedding_layer(self.vel_dims, embed_dims[3])
+        self.output_fc = embedding_layer(embed_dims[-1], embed_dims[-1]) if output_fc else None
+
+    def forward(self, box_3d):
+        pos_feat = self.pos_fc(box_3d[..., [X, Y, Z]])
+        size_feat = self.size_fc(box_3d[..., [W, L, H]])
+        yaw_feat = self.yaw_fc(box_3d[..., [SIN_YAW, COS_YAW]])
+        if self.mode == "add":
+            output = pos_feat + size_feat + yaw_feat
+        else:
+            output = torch.cat([pos_feat, size_feat, yaw_feat], dim=-1)
+        if self.vel_dims > 0:
+            vel_feat = self.vel_fc(box_3d[..., VX: VX + self.vel_dims])
+            output = output + vel_feat if self.mode == "add" else torch.cat([output, vel_feat], dim=-1)
+        if self.output_fc is not None:
+            output = self.output_fc(output)
+        return output
+
+
+@PLUGIN_LAYERS.register_module()
+class SparseBox3DRefinementModule(BaseModule):
+    """detection3d/blocks.py:77-154."""
+
+    def __init__(self, embed_dims=256, output_dim=11, num_cls=10, normalize_yaw=False, refine_yaw=False,
+                 with_cls_branch=True, with_quality_estimation=False):
+        super().__init__()
+        self.embed_dims = embed_dims
+        self.output_dim = output_dim
+        self.num_cls = num_cls
+        self.normalize_yaw = normalize_yaw
+        self.refine_yaw = refine_yaw
+        self.refine_state = [X, Y, Z, W, L, H]
+        if self.refine_yaw:
+            self.refine_state += [SIN_YAW, COS_YAW]
+        self.layers = nn.Sequential(*linear_relu_ln(embed_dims, 2, 2), Linear(self.embed_dims, self.output_dim),
+                                    Scale([1.0] * self.output_dim))
+        self.with_cls_branch = with_cls_branch
+        if with_cls_branch:
+            self.cls_layers = nn.Sequential(*linear_relu_ln(embed_dims, 1, 2), Linear(self.embed_dims, self.num_cls))
+        self.with_quality_estimation = with_quality_estimation
+        if with_quality_estimation:
+            self.quality_layers = nn.Sequential(*linear_relu_ln(embed_dims, 1, 2), Linear(self.embed_dims, 2))
+
+    def init_weight(self):
+        if self.with_cls_branch:
+            nn.init.constant_(self.cls_layers[-1].bias, bias_init_with_prob(0.01))
+
+    def forward(self, instance_feature, anchor, anchor_embed, time_interval=1.0, return_cls=True):
+        feature = instance_feature + anchor_embed
+        output = self.layers(feature)
+        # :133 adds the anchor on the refined states; written as one add of a masked anchor so no
+        # advanced-index scatter is launched (refine_state is a prefix 0..5 or 0..7)
+        n_ref = len(self.refine_state)
+        if not isinstance(time_interval, torch.Tensor):
+            time_interval = instance_feature.new_tensor(time_interval)
+        head = output[..., :n_ref] + anchor[..., :n_ref]
+        parts = [head]
+        if n_ref < VX:
+            parts.append(output[..., n_ref:VX])
+        if self.normalize_yaw:
+            raise NotImplementedError("normalize_yaw is off in the SimPB configs")
+        if self.output_dim > 8:
+            ti = time_interval.reshape(-1, *([1] * (output.dim() - 1))) if time_interval.dim() else time_interval
+            parts.append(output[..., VX:] / ti + anchor[..., VX:])  # :138-143
+        output = torch.cat(parts, dim=-1)
+        if return_cls:
+            assert self.with_cls_branch, "Without classification layers !!!"
+            cls = self.cls_layers(instance_feature)
+        else:
+            cls = None
+        quality = self.quality_layers(feature) if return_cls and self.with_quality_estimation else None
+        return output, cls, quality
+
+
+@PLUGIN_LAYERS.register_module()
+class SparseBox3DKeyPointsGenerator(BaseModule):
+    """detection3d/blocks.py:157-284 (no temporal key points: the SimPB configs never pass
+    T_cur2temp_list)."""
+
+    def __init__(self, embed_dims=256, num_learnable_pts=0, fix_scale=None):
+        super().__init__()
+        self.embed_dims = embed_dims
+        self.num_learnable_pts = num_learnable_pts
+        if fix_scale is None:
+            fix_scale = ((0.0, 0.0, 0.0),)
+        self.fix_scale = nn.Parameter(torch.tensor(fix_scale, dtype=torch.float32), requires_grad=False)
+        self.num_pts = len(self.fix_scale) + num_learnable_pts
+        if num_learnable_pts > 0:
+            self.learnable_fc = Linear(self.embed_dims, num_learnable_pts * 3)
+
+    def init_weight(self):
+        if self.num_learnable_pts > 0:
+            nn.init.xavier_uniform_(self.learnable_fc.weight)
+            nn.init.constant_(self.learnable_fc.bias, 0.0)
+
+    def forward(self, anchor, instance_feature=None, T_cur2temp_list=None, cur_timestamp=None, temp_timestamps=None):
+        if T_cur2temp_list is not None or temp_timestamps is not None:
+            raise NotImplementedError("temporal key points are not used by the SimPB configs")
+        bs, num_anchor = anchor.shape[:2]
+        size = anchor[..., None, [W, L, H]].exp()
+        key_points = self.fix_scale * size
+        if self.num_learnable_pts > 0 and instance_feature is not None:
+            learnable_scale = (
+                self.learnable_fc(instance_feature).reshape(bs, num_anchor, self.num_learnable_pts, 3).sigmoid() - 0.5)
+            key_points = torch.cat([key_points, learnable_scale * size], dim=-2)
+        cos, sin = anchor[..., None, COS_YAW], anchor[..., None, SIN_YAW]
+        # rotation about z (:202-212) written out instead of building a 3x3 per anchor
+        x = cos * key_points[..., 0] - sin * key_points[..., 1]
+        y = sin * key_points[..., 0] + cos * key_points[..., 1]
+        key_points = torch.stack([x, y, key_points[..., 2]], dim=-1)
+        return key_points + anchor[..., None, [X, Y, Z]]
+
+    @staticmethod
+    def anchor_projection(anchor, T_src2dst_list, src_timestamp=None, dst_timestamps=None, time_intervals=None):
+        """detection3d/blocks.py:248-280 including its acknowledged quirk (:271-278): the yaw pair
+        is rotated as [cos, sin] and written back in that order into the [sin, cos] slots."""
+        dst_anchors = []
+        for i in range(len(T_src2dst_list)):
+            vel = anchor[..., VX:]
+            vel_dim = vel.shape[-1]
+            T_src2dst = torch.unsqueeze(T_src2dst_list[i].to(dtype=anchor.dtype), dim=1)
+            center = anchor[..., [X, Y, Z]]
+            if time_intervals is not None:
+                time_interval = time_intervals[i]
+            elif src_timestamp is not None and dst_timestamps is not None:
+                time_interval = (src_timestamp - dst_timestamps[i]).to(dtype=vel.dtype)
+            else:
+                time_interval = None
+            if time_interval is not None:
+                center = center - vel * time_interval[:, None, None]
+            center = torch.matmul(T_src2dst[..., :3, :3], center[..., None]).squeeze(dim=-1) + T_src2dst[..., :3, 3]
+            size = anchor[..., [W, L, H]]
+            yaw = torch.matmul(T_src2dst[..., :2, :2], anchor[..., [COS_YAW, SIN_YAW], None]).squeeze(-1)
+            vel = torch.matmul(T_src2dst[..., :vel_dim, :vel_dim], vel[..., None]).squeeze(-1)
+            dst_anchors.append(torch.cat([center, size, yaw, vel], dim=-1))
+        return dst_anchors
+
+    @staticmethod
+    def distance(anchor):
+        return torch.norm(anchor[..., :2], p=2, dim=-1)
+
+
+def bbox_cxcywh_to_xyxy(bbox):
+    """mmdet.core.bbox.transforms.bbox_cxcywh_to_xyxy [mmdet 2.28.2, restated]."""
+    cx, cy, w, h = bbox.split((1, 1, 1, 1), dim=-1)
+    return torch.cat([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+
+@BBOX_CODERS.register_module()
+class SparseBox3DDecoder(object):
+    """detection3d/decoder.py:9-252. Everything up to the final per-sample packing stays on the
+    device; outputs are moved to the host once per field like the reference does (:230-251)."""
+
+    def __init__(self, num_output=300, score_threshold=None, sorted=True):
+        self.num_output = num_output
+        self.score_threshold = score_threshold
+        self.sorted = sorted
+
+    def decode_box(self, box):
+        yaw = torch.atan2(box[:, SIN_YAW], box[:, COS_YAW])
+        return torch.cat([box[:, [X, Y, Z]], box[:, [W, L, H]].exp(), yaw[:, None], box[:, VX:]], dim=-1)
+
+    def decode_box2d(self, box, aug_config):
+        crop = aug_config["crop"]
+        scale_factor = aug_config["resize"]
+        crop_img_size = (crop[2] - crop[0], crop[3] - crop[1])
+        box = bbox_cxcywh_to_xyxy(box)
+        box[..., 0::2] = (box[..., 0::2] * crop_img_size[0]).clamp(min=0, max=crop_img_size[0])
+        box[..., 1::2] = (box[..., 1::2] * crop_img_size[1]).clamp(min=0, max=crop_img_size[1]) + crop[1]
+        return box / scale_factor
+
+    def _rank(self, cls_scores, qulity, output_idx, squeeze_cls):
+        """The shared top-k / centerness re-score / sort prologue (:133-167 == :59-93)."""
+        cls_scores = cls_scores[output_idx].sigmoid()
+        cls_ids = None
+        if squeeze_cls:
+            cls_scores, cls_ids = cls_scores.max(dim=-1)
+            cls_scores = cls_scores.unsqueeze(dim=-1)
+        bs, num_pred, num_cls = cls_scores.shape
+        cls_scores, indices = cls_scores.flatten(start_dim=1).topk(self.num_output, dim=1, sorted=self.sorted)
+        if not squeeze_cls:
+            cls_ids = indices % num_cls
+        mask = cls_scores >= self.score_threshold if self.score_threshold is not None else None
+        cls_scores_origin = None
+        if qulity is not None:
+            centerness = torch.gather(qulity[output_idx][..., CNS], 1, indices // num_cls)
+            cls_scores_origin = cls_scores.clone()
+            cls_scores = cls_scores * centerness.sigmoid()
+            cls_scores, idx = torch.sort(cls_scores, dim=1, descending=True)
+            if not squeeze_cls:
+                cls_ids = torch.gather(cls_ids, 1, idx)
+            if mask is not None:
+                mask = torch.gather(mask, 1, idx)
+            indices = torch.gather(indices, 1, idx)
+        return cls_scores, cls_scores_origin, cls_ids, indices, mask, num_cls
+
+    def decode(self, cls_scores, box_preds, instance_id=None, qulity=None, output_idx=-1):
+        squeeze_cls = instance_id is not None
+        cls_scores, origin, cls_ids, indices, mask, num_cls = self._rank(cls_scores, qulity, output_idx, squeeze_cls)
+        box_preds = box_preds[output_idx]
+        output = []
+        for i in range(cls_scores.shape[0]):
+            category_ids = cls_ids[i][indices[i]] if squeeze_cls else cls_ids[i]
+            scores = cls_scores[i]
+            box = box_preds[i, indices[i] // num_cls]
+            if mask is not None:
+                category_ids, scores, box = category_ids[mask[i]], scores[mask[i]], box[mask[i]]
+            out = {"boxes_3d": self.decode_box(box).cpu(), "scores_3d": scores.cpu(), "labels_3d": category_ids.cpu()}
+            if origin is not None:
+                out["cls_scores"] = (origin[i][mask[i]] if mask is not None else origin[i]).cpu()
+            if instance_id is not None:
+                ids = instance_id[i, indices[i]]
+                out["instance_ids"] = ids[mask[i]] if mask is not None else ids
+            output.append(out)
+        return output
+
+    def decode_with2d(self, cls_scores, box_preds, instance_id=None, qulity=None, output_idx=-1, cls_scores2d=None,
+                      box_preds2d=None, trans_matrix=None, query_groups=None, output_idx2d=-1, aug_configs=None,
+                      with_association=False):
+        """decoder.py:124-252. `trans_matrix[k]` may be the reference's dense one-hot
+        [bs, N2, N3] tensor or an index table q2a i32[bs, N2] (slot -> anchor, -1 for pads)."""
+        squeeze_cls = instance_id is not None
+        cls_scores, origin, cls_ids, indices, mask, num_cls = self._rank(cls_scores, qulity, output_idx, squeeze_cls)
+        box_preds = box_preds[output_idx]
+        cls_scores2d = cls_scores2d[output_idx2d]
+        box_preds2d = box_preds2d[output_idx2d]
+        trans = trans_matrix[output_idx2d]
+        query_groups = query_groups[output_idx2d]
+        aug_config = aug_configs[0]
+        num_anchor = box_preds.shape[1]
+        output = []
+        for i in range(cls_scores.shape[0]):
+            category_ids = cls_ids[i][indices[i]] if squeeze_cls else cls_ids[i]
+            scores = cls_scores[i]
+            box = box_preds[i, indices[i] // num_cls]
+            assert num_cls == 1
+            if with_association:
+                if trans.dtype in (torch.int32, torch.int64):  # index form: slot -> anchor
+                    q2a = trans[i].long()
+                    rank_of_anchor = torch.full((num_anchor + 1,), -1, dtype=torch.long, device=q2a.device)
+                    rank_of_anchor[indices[i]] = torch.arange(indices.shape[1], device=q2a.device)
+                    rank = rank_of_anchor[torch.where(q2a >= 0, q2a, num_anchor)]
+                    indices2d = torch.where(rank >= 0)[0]
+                    trans_t = torch.zeros(indices.shape[1], len(indices2d), device=q2a.device)
+                    trans_t[rank[indices2d], torch.arange(len(indices2d), device=q2a.device)] = 1.0
+                    trans_t = trans_t.cpu()
+                else:
+                    trans_t = trans[i].permute(1, 0)[indices[i]]
+                    indices2d = torch.where(trans_t.any(0))[0]
+                    trans_t = torch.index_select(trans_t, 1, indices2d).cpu()
+            else:
+                indices2d = torch.arange(len(box_preds2d[i]), device=box_preds2d.device)
+                trans_t = None
+            idx2d_host = indices2d.cpu()
+            camidx_2d, query_groups_new = [], []
+            for cam_idx, qg in enumerate(query_groups):
+                parts_index = torch.where(torch.logical_and(qg[0] <= idx2d_host, idx2d_host < qg[1]))[0]
+                if len(parts_index) > 0:
+                    qg_new = (parts_index[0].item(), parts_index[-1].item() + 1)
+                elif len(query_groups_new) > 0:
+                    qg_new = (query_groups_new[-1][-1], query_groups_new[-1][-1])
+                else:
+                    qg_new = (0, 0)
+                camidx_2d.append(torch.ones((len(parts_index))) * cam_idx)
+                query_groups_new.append(qg_new)
+            camidx_2d = torch.cat(camidx_2d, dim=0)
+            query_groups = query_groups_new  # the reference re-binds the loop variable (:216)
+            scores2d, category_ids2d = cls_scores2d[i, indices2d].sigmoid().max(dim=-1)
+            box2d = self.decode_box2d(box_preds2d[i, indices2d], aug_config)
+            if mask is not None:
+                category_ids, scores, box = category_ids[mask[i]], scores[mask[i]], box[mask[i]]
+            out = {
+                "boxes_3d": self.decode_box(box).cpu(), "scores_3d": scores.cpu(), "labels_3d": category_ids.cpu(),
+                "boxes_2d": box2d.cpu(), "scores_2d": scores2d.cpu(), "labels_2d": category_ids2d.cpu(),
+                "camidx_2d": camidx_2d, "trans_matrix": trans_t, "query_groups": query_groups,
+            }
+            if origin is not None:
+                out["cls_scores"] = (origin[i][mask[i]] if mask is not None else origin[i]).cpu()
+            if instance_id is not None:
+                ids = instance_id[i, indices[i]]
+                out["instance_ids"] = ids[mask[i]] if mask is not None else ids
+            output.append(out)
+        return output

@@ -1,0 +1,183 @@
+"""models/simpb.py of the reference (the SimPB detector) plus the two mmdet 2.28.2 classes it
+builds and which are not vendored there: ResNet (style='pytorch') and FPN. Parameter names follow
+mmdet so released checkpoints load: img_backbone.{conv1,bn1,layer{1-4}.{i}.{conv,bn}{1-3},
+downsample.{0,1}}, img_neck.{lateral_convs,fpn_convs}.{i}.conv.* [mmdet, restated].
+
+This is SURVEY.md §8(f) item 1 ("next": caller of the hot path): it runs on PyTorch-ROCm/MIOpen
+in fp16 + channels_last, and hands the head a channel-last token buffer without the 92 MB
+permute the reference pays in feature_maps_format (ops/__init__.py:78)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import BaseModule
+from .ops import feature_maps_format
+from .registry import BACKBONES, DETECTORS, HEADS, NECKS, PLUGIN_LAYERS, build_from_cfg
+
+__all__ = ["SimPB", "ResNet", "FPN"]
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        # style='pytorch': the stride sits on the 3x3 conv
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+@BACKBONES.register_module()
+class ResNet(BaseModule):
+    arch_settings = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth, in_channels=3, num_stages=4, strides=(1, 2, 2, 2), out_indices=(0, 1, 2, 3),
+                 style="pytorch", frozen_stages=-1, norm_cfg=dict(type="BN", requires_grad=True), norm_eval=True,
+                 with_cp=False, pretrained=None, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        if depth not in self.arch_settings or style != "pytorch":
+            raise NotImplementedError("ResNet-50/101/152 with style='pytorch' (the SimPB configs)")
+        self.depth = depth
+        self.out_indices = out_indices
+        self.pretrained = pretrained
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inplanes = 64
+        self.res_layers = []
+        for i, blocks in enumerate(self.arch_settings[depth][:num_stages]):
+            planes = 64 * 2 ** i
+            layers = []
+            for j in range(blocks):
+                stride = strides[i] if j == 0 else 1
+                down = None
+                if j == 0 and (stride != 1 or inplanes != planes * 4):
+                    down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                         nn.BatchNorm2d(planes * 4))
+                layers.append(Bottleneck(inplanes, planes, stride, down))
+                inplanes = planes * 4
+            name = f"layer{i + 1}"
+            self.add_module(name, nn.Sequential(*layers))
+            self.res_layers.append(name)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+class ConvModule(nn.Module):
+    """mmcv ConvModule without norm/activation: parameters live under `.conv`."""
+
+    def __init__(self, cin, cout, k, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+@NECKS.register_module()
+class FPN(BaseModule):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None, norm_cfg=None, act_cfg=None,
+                 upsample_cfg=dict(mode="nearest"), init_cfg=None):
+        super().__init__(init_cfg)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_ins = len(in_channels)
+        self.num_outs = num_outs
+        self.start_level = start_level
+        self.backbone_end_level = self.num_ins if end_level in (-1, self.num_ins - 1) else end_level + 1
+        if num_outs != self.backbone_end_level - start_level:
+            raise NotImplementedError("extra FPN levels are not used by the SimPB configs (num_outs == num_ins)")
+        self.upsample_cfg = dict(upsample_cfg)
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1))
+
+    def forward(self, inputs):
+        laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+        for i in range(len(laterals) - 1, 0, -1):
+            laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
+                                                              **self.upsample_cfg)
+        return tuple(self.fpn_convs[i](laterals[i]) for i in range(len(laterals)))
+
+
+@DETECTORS.register_module()
+class SimPB(BaseModule):
+    """models/simpb.py:25-129, inference path (simple_test)."""
+
+    def __init__(self, img_backbone, head, img_neck=None, init_cfg=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, use_grid_mask=True, use_deformable_func=False, depth_branch=None):
+        super().__init__(init_cfg)
+        self.img_backbone = build_from_cfg(img_backbone, BACKBONES)
+        if img_neck is not None:
+            self.img_neck = build_from_cfg(img_neck, NECKS)
+        else:
+            self.img_neck = None
+        self.head = build_from_cfg(head, HEADS)
+        self.use_grid_mask = use_grid_mask  # GridMask is a training augmentation (grid_mask.py:93 returns x in eval)
+        if not use_deformable_func:
+            raise NotImplementedError("use_deformable_func=True is what the SimPB configs ship (config :55)")
+        self.use_deformable_func = use_deformable_func
+        self.head.use_deformable_func = use_deformable_func
+        self.depth_branch = build_from_cfg(depth_branch, PLUGIN_LAYERS) if depth_branch is not None else None
+        self.fp16_enabled = False
+
+    def half_backbone(self):
+        """wrap_fp16_model (tools/test.py:239-241) + @auto_fp16(apply_to=('img',), out_fp32=True)
+        (simpb.py:63): backbone and neck in fp16, everything after in fp32. channels_last so the
+        convolutions produce NHWC, which is already the head's token layout."""
+        self.img_backbone.half().to(memory_format=torch.channels_last)
+        if self.img_neck is not None:
+            self.img_neck.half().to(memory_format=torch.channels_last)
+        self.fp16_enabled = True
+        return self
+
+    def extract_feat(self, img, return_depth=False, metas=None):
+        """simpb.py:64-91."""
+        bs = img.shape[0]
+        if img.dim() == 5:
+            num_cams = img.shape[1]
+            img = img.flatten(end_dim=1)
+        else:
+            num_cams = 1
+        if self.fp16_enabled:
+            img = img.half().contiguous(memory_format=torch.channels_last)
+        feature_maps = self.img_backbone(img)
+        if self.img_neck is not None:
+            feature_maps = list(self.img_neck(feature_maps))
+        feature_maps = [f.float() if self.fp16_enabled else f for f in feature_maps]
+        feature_maps = [torch.reshape(f, (bs, num_cams) + f.shape[1:]) for f in feature_maps]
+        return feature_maps_format(feature_maps)
+
+    def forward(self, img, **data):
+        if self.training:
+            raise NotImplementedError("training is out of scope of this path")
+        return self.simple_test(img, **data)
+
+    def simple_test(self, img, **data):
+        feature_maps = self.extract_feat(img)
+        model_outs = self.head(feature_maps, data)
+        return self.head.post_process(model_outs, data)

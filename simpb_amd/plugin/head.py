@@ -1,0 +1,278 @@
+"""models/simpb_head.py of the reference: SimPBHead, inference path (forward :323-747 and
+post_process :1089-1123). The 50-entry operation_order interpreter, the module names and the
+parameter names are the reference's; the data movement between operators uses index tables from
+the allocation kernels instead of one-hot matrices."""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import training_stubs  # noqa: F401  (registers the inert training-only classes)
+from .allocation import gather_rows
+from .registry import (ATTENTION, BBOX_CODERS, BBOX_SAMPLERS, FEEDFORWARD_NETWORK, HEADS, LOSSES, NORM_LAYERS,
+                       PLUGIN_LAYERS, POSITIONAL_ENCODING, TRANSFORMER_LAYER_SEQUENCE, build_from_cfg)
+from .layers import BaseModule
+
+__all__ = ["SimPBHead"]
+
+
+@HEADS.register_module()
+class SimPBHead(BaseModule):
+    def __init__(self, instance_bank: dict, anchor_encoder: dict, graph_model: dict, norm_layer: dict, ffn: dict,
+                 deformable_model: dict, num_cams: int = 6, num_decoder: int = 6, num_single_frame_decoder: int = -1,
+                 temp_graph_model: dict = None, loss_cls: dict = None, loss_reg: dict = None, decoder: dict = None,
+                 sampler: dict = None, reg_weights: List = None, operation_order: Optional[List[str]] = None,
+                 cls_threshold_to_reg: float = -1, dn_loss_weight: float = 5.0, decouple_attn: bool = True,
+                 init_cfg: dict = None, enable2d=False, enable3d=True, embed_dims=256, num_levels=4, num_anchor=900,
+                 encoder2d=None, share_encoder2d=False, anchor_encoder2d=None, positional_encoding=None,
+                 qg_self_attn=None, qg_cross_attn=None, refine_layer2d=None, refine_layer3d=None,
+                 decouple_attn2d=False, with_allocate_attn_mask=False, dynamic_allocation=None,
+                 adaptive_aggregation=None, coster2d=None, coster3d=None, denoise2d=None, loss_cls2d=None,
+                 loss_iou2d=None, loss_bbox2d=None, loss_alpha2d=None, loss_depth2d=None, **kwargs):
+        super().__init__(init_cfg)
+        if encoder2d is not None:
+            raise NotImplementedError("the 2D encoder variant ('SimPB' non-plus) has no released config "
+                                      "(SURVEY.md §8f item 4)")
+        if not (decouple_attn and enable3d):
+            raise NotImplementedError("the SimPB configs use decouple_attn=True, enable3d=True")
+        self.enable2d = enable2d
+        self.enable3d = enable3d
+        self.embed_dims = embed_dims
+        self.num_cams = num_cams
+        self.num_levels = num_levels
+        self.num_anchor = num_anchor
+        self.num_decoder = num_decoder
+        self.num_single_frame_decoder = num_single_frame_decoder
+        self.dn_loss_weight = dn_loss_weight
+        self.decouple_attn = decouple_attn
+        self.decouple_attn2d = decouple_attn2d
+        self.cls_threshold_to_reg = cls_threshold_to_reg
+        self.reg_weights = [1.0] * 10 if reg_weights is None else reg_weights
+        if operation_order is None:
+            operation_order = ["temp_gnn", "gnn", "norm", "deformable", "norm", "ffn", "norm", "refine3d"] * num_decoder
+            operation_order = operation_order[3:]
+        self.operation_order = list(operation_order)
+
+        def build(cfg, registry):
+            return None if cfg is None else build_from_cfg(cfg, registry)
+
+        self.with_denoise2d = False
+        if self.enable2d:
+            self.encoder2d = None
+            if anchor_encoder2d is None:
+                raise NotImplementedError("the SimPB configs always give anchor_encoder2d")
+            self.anchor_encoder2d = build(anchor_encoder2d, POSITIONAL_ENCODING)
+            self.instance_status = "3d"
+            self.share_encoder2d = share_encoder2d
+            self.with_allocate_attn_mask = with_allocate_attn_mask
+            self.loss_cls2d = build(loss_cls2d, LOSSES)
+            self.loss_iou2d = build(loss_iou2d, LOSSES)
+            self.loss_bbox2d = build(loss_bbox2d, LOSSES)
+            self.loss_alpha2d = build(loss_alpha2d, LOSSES)
+            self.loss_depth2d = build(loss_depth2d, LOSSES)
+            if denoise2d is not None:
+                self.with_denoise2d = True
+                self.denoise2d = build(denoise2d, PLUGIN_LAYERS)
+            self.coster2d = build(coster2d, BBOX_SAMPLERS)
+        self.instance_bank = build(instance_bank, PLUGIN_LAYERS)
+        self.anchor_encoder = build(anchor_encoder, POSITIONAL_ENCODING)
+        self.sampler = build(sampler, BBOX_SAMPLERS)
+        self.decoder = build(decoder, BBOX_CODERS)
+        self.loss_cls = build(loss_cls, LOSSES)
+        self.loss_reg = build(loss_reg, LOSSES)
+        self.op_config_map = {
+            "ffn": [ffn, FEEDFORWARD_NETWORK],
+            "norm": [norm_layer, NORM_LAYERS],
+            "allocation": [dynamic_allocation, PLUGIN_LAYERS],
+            "aggregation": [adaptive_aggregation, PLUGIN_LAYERS],
+            "qg_self_attn": [qg_self_attn, ATTENTION],
+            "qg_cross_attn": [qg_cross_attn, ATTENTION],
+            "refine2d": [refine_layer2d, PLUGIN_LAYERS],
+            "gnn": [graph_model, ATTENTION],
+            "temp_gnn": [temp_graph_model, ATTENTION],
+            "deformable": [deformable_model, ATTENTION],
+            "refine3d": [refine_layer3d, PLUGIN_LAYERS],
+        }
+        self.layers = nn.ModuleList([build(*self.op_config_map.get(op, [None, None])) for op in self.operation_order])
+        self.fc_before = nn.Linear(self.embed_dims, self.embed_dims * 2, bias=False)
+        self.fc_after = nn.Linear(self.embed_dims * 2, self.embed_dims, bias=False)
+        if self.decouple_attn2d and self.enable2d:
+            self.fc_before2d = nn.Linear(self.embed_dims, self.embed_dims * 2, bias=False)
+            self.fc_after2d = nn.Linear(self.embed_dims * 2, self.embed_dims, bias=False)
+        else:
+            self.fc_before2d = nn.Identity()
+            self.fc_after2d = nn.Identity()
+        self.use_deformable_func = True  # set by SimPB.__init__ in the reference (simpb.py:53)
+        self._tables = None
+
+    def init_weights(self):
+        """simpb_head.py:202-212."""
+        for i, op in enumerate(self.operation_order):
+            if self.layers[i] is None:
+                continue
+            for p in self.layers[i].parameters():
+                if p.dim() > 1:
+                    nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if hasattr(m, "init_weight"):
+                m.init_weight()
+
+    # ------------------------------------------------------------------ feature-map tables
+    def prepare2d(self, feature_maps, metas):
+        """simpb_head.py:281-292 (encoder-less branch): the channel-last token buffer viewed per
+        camera, plus i32/i64 copies of the (H, W, start) tables cached across frames."""
+        if not self.use_deformable_func:
+            raise RuntimeError("SimPBHead needs use_deformable_func=True (simpb_head.py:293-294)")
+        col, spatial_shape, scale_start = feature_maps[:3]
+        bs, _, dim = col.shape
+        nc = len(spatial_shape)
+        key = (spatial_shape.data_ptr(), scale_start.data_ptr(), col.device)
+        if self._tables is None or self._tables[0] != key:
+            self._tables = (key, spatial_shape.int().contiguous(), scale_start.int().contiguous(),
+                            spatial_shape[0].long().contiguous(), scale_start[0].long().contiguous())
+        _, ss32, st32, ss_cam, st_cam = self._tables
+        feat_flatten = col.reshape(bs, nc, -1, dim).flatten(0, 1)
+        encoder2d_dict = {
+            "value": feat_flatten,
+            "key_padding_mask": None,  # all-False in the reference (:286): masked_fill would be a no-op
+            "spatial_shapes": ss_cam,
+            "level_start_index": st_cam,
+        }
+        return encoder2d_dict, [col, ss32, st32]
+
+    # ------------------------------------------------------------------ decoupled attention
+    def graph_model(self, index, query, key=None, value=None, query_pos=None, key_pos=None, **kwargs):
+        """simpb_head.py:298-310."""
+        query = torch.cat([query, query_pos], dim=-1)
+        key = torch.cat([key, key_pos], dim=-1) if key is not None else None
+        value = self.fc_before(value) if value is not None else None
+        layer = self.layers[index] if isinstance(index, int) else index
+        kwargs.pop("attn_mask", None)
+        return self.fc_after(layer(query, key, value, query_pos=None, key_pos=None, **kwargs))
+
+    def graph_model2d(self, index, query, key=None, value=None, query_pos=None, key_pos=None, **kwargs):
+        """simpb_head.py:312-321."""
+        if self.decouple_attn2d:
+            query = torch.cat([query, query_pos], dim=-1)
+            key = torch.cat([key, key_pos], dim=-1) if key is not None else None
+            query_pos, key_pos = None, None
+        value = self.fc_before2d(value) if value is not None else None
+        return self.fc_after2d(self.layers[index](query, key, value, query_pos=query_pos, key_pos=key_pos, **kwargs))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, feature_maps, metas: dict):
+        if self.training:
+            raise NotImplementedError("SimPBHead here is the inference path; training (denoising, losses) is out of scope")
+        if isinstance(feature_maps, torch.Tensor):
+            feature_maps = [feature_maps]
+        batch_size = feature_maps[0].shape[0]
+        if self.sampler is not None and self.sampler.dn_metas is not None:
+            self.sampler.dn_metas = None  # :333-334; never set in eval
+
+        instance_feature, anchor, temp_instance_feature, temp_anchor, time_interval = self.instance_bank.get(
+            batch_size, metas, dn_metas=None)
+        anchor_embed = self.anchor_encoder(anchor)
+        temp_anchor_embed = self.anchor_encoder(temp_anchor) if temp_anchor is not None else None
+
+        quality, prediction, classification = [], [], []
+        prediction2d, classification2d, prediction_alpha2d, prediction_depth2d = [], [], [], []
+        ref_pts2d_list, ref_trans_shape_list, ref_trans_matrix_list, ref_query_groups_list = [], [], [], []
+        temp_attn_instance = instance_feature
+        encoder2d_dict, feature_maps = self.prepare2d(feature_maps, metas)
+        alloc = None
+        last = len(self.operation_order) - 1
+
+        for i, op in enumerate(self.operation_order):
+            layer = self.layers[i]
+            if layer is None:
+                continue
+            elif op == "norm" or op == "ffn":
+                instance_feature = layer(instance_feature)
+            elif op == "allocation":
+                assert self.instance_status == "3d"
+                anchor2d, ref_depth2d, ref_trans_mask, ref_trans_shape, _, _, ref_query_groups, _ = layer(
+                    anchor, metas, dense=False)
+                alloc = layer.last
+                instance_feature = gather_rows(instance_feature, alloc.q2a)  # :438
+                anchor_embed2d = self.anchor_encoder2d(anchor2d)
+                ref_pts2d_list.append(anchor2d[..., :2])
+                self.instance_status = "2d"
+            elif op == "aggregation":
+                assert self.instance_status == "2d"
+                instance_feature, anchor_embed, anchor = layer(
+                    query2d=instance_feature, query_pos2d=anchor_embed2d, anchor2d=anchor2d,
+                    query3d=temp_attn_instance, query_pos3d=anchor_embed, anchor3d=anchor,
+                    allocation=alloc, attn_mask=None, graph_model=self.graph_model)
+                self.instance_status = "3d"
+            elif op == "qg_self_attn":
+                instance_feature = self.graph_model2d(i, query=instance_feature, value=instance_feature,
+                                                      query_pos=anchor_embed2d, query_groups=ref_query_groups)
+            elif op == "qg_cross_attn":
+                instance_feature = layer(query=instance_feature, query_pos=anchor_embed2d,
+                                         reference_points=anchor2d.unsqueeze(2), query_groups=ref_query_groups,
+                                         query_cam=alloc.query_cam, **encoder2d_dict)
+            elif op == "refine2d":
+                anchor2d, cls2d, depth2d, alpha2d = layer(instance_feature, anchor2d, anchor_embed2d, metas=metas,
+                                                          query_groups=ref_query_groups)
+                prediction2d.append(anchor2d)
+                classification2d.append(cls2d)
+                prediction_alpha2d.append(alpha2d)
+                prediction_depth2d.append(depth2d)
+                ref_trans_shape_list.append(ref_trans_shape)
+                ref_trans_matrix_list.append(alloc.q2a)  # index form of ref_trans_matrix
+                ref_query_groups_list.append(ref_query_groups)
+            elif op == "gnn":
+                instance_feature = self.graph_model(i, instance_feature, value=instance_feature, query_pos=anchor_embed)
+            elif op == "temp_gnn":
+                instance_feature = self.graph_model(i, instance_feature, temp_instance_feature, temp_instance_feature,
+                                                    query_pos=anchor_embed, key_pos=temp_anchor_embed)
+                temp_attn_instance = instance_feature
+            elif op == "deformable":
+                instance_feature = layer(instance_feature, anchor, anchor_embed, feature_maps, metas)
+            elif op == "refine3d":
+                anchor, cls, qt = layer(
+                    instance_feature, anchor, anchor_embed, time_interval=time_interval,
+                    return_cls=(len(prediction) == self.num_single_frame_decoder - 1 or i == last))
+                prediction.append(anchor)
+                classification.append(cls)
+                quality.append(qt)
+                if len(prediction) == self.num_single_frame_decoder:
+                    instance_feature, anchor = self.instance_bank.update(instance_feature, anchor, cls)
+                if i != last:
+                    anchor_embed = self.anchor_encoder(anchor)
+                if len(prediction) > self.num_single_frame_decoder and temp_anchor_embed is not None:
+                    temp_anchor_embed = anchor_embed[:, : self.instance_bank.num_temp_instances]
+            else:
+                raise NotImplementedError(f"{op} is not supported.")
+
+        output = {
+            "quality": quality, "prediction": prediction, "classification": classification,
+            "prediction2d": prediction2d, "classification2d": classification2d,
+            "prediction_alpha2d": prediction_alpha2d, "prediction_depth2d": prediction_depth2d,
+            "ref_pts2d_list": ref_pts2d_list, "ref_trans_shape_list": ref_trans_shape_list,
+            "ref_trans_matrix_list": ref_trans_matrix_list, "ref_query_groups_list": ref_query_groups_list,
+        }
+        self.instance_bank.cache(instance_feature, anchor, cls, metas, feature_maps)
+        output["instance_id"] = self.instance_bank.get_instance_id(cls, anchor, self.decoder.score_threshold)
+        return output
+
+    def loss(self, model_outs, data):
+        raise NotImplementedError("training losses (simpb_head.py:749-1086) are out of scope of this path")
+
+    def post_process(self, model_outs, data, output_idx=-1, output_idx2d=-1):
+        """simpb_head.py:1089-1123."""
+        results = [dict() for _ in data["img_metas"]]
+        if self.enable2d:
+            aug_configs = [m["aug_config"] for m in data["img_metas"]]
+            results_3d = self.decoder.decode_with2d(
+                model_outs["classification"], model_outs["prediction"], model_outs.get("instance_id"),
+                model_outs.get("quality"), output_idx, model_outs["classification2d"], model_outs["prediction2d"],
+                model_outs["ref_trans_matrix_list"], model_outs["ref_query_groups_list"], output_idx2d, aug_configs,
+                with_association=True)
+        else:
+            results_3d = self.decoder.decode(model_outs["classification"], model_outs["prediction"],
+                                             model_outs.get("instance_id"), model_outs.get("quality"),
+                                             output_idx=output_idx)
+        for i, result_3d in enumerate(results_3d):
+            results[i]["img_bbox"] = result_3d
+        return results

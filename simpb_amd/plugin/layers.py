@@ -1,0 +1,162 @@
+"""Small building blocks shared by the plugin modules: the stand-ins for the handful of mmcv
+classes the reference's models import (Linear, Scale, BaseModule, Sequential, build_* helpers,
+MultiheadAttention) so that parameter names line up with released checkpoints
+(SURVEY.md §8b "Checkpoint compatibility")."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .registry import ATTENTION, NORM_LAYERS
+
+Linear = nn.Linear
+NORM_LAYERS.register_module("LN", module=nn.LayerNorm)
+
+
+class BaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+
+class Sequential(nn.Sequential):
+    pass
+
+
+class Scale(nn.Module):
+    """mmcv.cnn.Scale: a learnable per-element multiplier stored under `.scale`."""
+
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+def bias_init_with_prob(prior_prob):
+    return float(-math.log((1 - prior_prob) / prior_prob))
+
+
+def build_norm_layer(cfg, num_features):
+    cfg = dict(cfg)
+    typ = cfg.pop("type")
+    cfg.pop("requires_grad", None)
+    if typ != "LN":
+        raise KeyError(f"norm layer {typ} is not used on this path")
+    return "ln", nn.LayerNorm(num_features, **cfg)
+
+
+def build_activation_layer(cfg):
+    cfg = dict(cfg)
+    typ = cfg.pop("type")
+    return {"ReLU": nn.ReLU, "GELU": nn.GELU, "Sigmoid": nn.Sigmoid}[typ](**cfg)
+
+
+def build_dropout(cfg):
+    cfg = dict(cfg)
+    if cfg.pop("type") != "Dropout":
+        raise KeyError("only Dropout is used on this path")
+    return nn.Dropout(p=cfg.get("drop_prob", 0.5), inplace=cfg.get("inplace", False))
+
+
+def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
+    """models/blocks.py:32-43."""
+    if input_dims is None:
+        input_dims = embed_dims
+    layers = []
+    for _ in range(out_loops):
+        for _ in range(in_loops):
+            layers.append(Linear(input_dims, embed_dims))
+            layers.append(nn.ReLU(inplace=True))
+            input_dims = embed_dims
+        layers.append(nn.LayerNorm(embed_dims))
+    return layers
+
+
+def mha_forward(attn, query, key, value, groups=None, same_qk=False):
+    """Arithmetic of torch.nn.MultiheadAttention.forward for batch-first [bs, N, E] inputs, using
+    `attn` (an nn.MultiheadAttention) purely as the parameter container so checkpoint keys stay
+    `attn.in_proj_weight/in_proj_bias/out_proj.*`.
+
+    groups: list of (start, end) query/key blocks. The reference builds an N x N additive mask
+    that is 0 inside a block and -inf across (group_attn.py:104-113); softmax under that mask is
+    exactly an independent softmax per block, which is what is computed here (no mask tensor,
+    ~1/len(groups) of the score work)."""
+    e = attn.embed_dim
+    h = attn.num_heads
+    hd = e // h
+    w, b = attn.in_proj_weight, attn.in_proj_bias
+    bs, nq, _ = query.shape
+    if same_qk:
+        qk = F.linear(query, w[: 2 * e], b[: 2 * e])
+        q, k = qk[..., :e], qk[..., e:]
+    else:
+        q = F.linear(query, w[:e], b[:e])
+        k = F.linear(key, w[e: 2 * e], b[e: 2 * e])
+    v = F.linear(value, w[2 * e:], b[2 * e:])
+    q = q.reshape(bs, nq, h, hd).transpose(1, 2)
+    k = k.reshape(bs, -1, h, hd).transpose(1, 2)
+    v = v.reshape(bs, -1, h, hd).transpose(1, 2)
+    if groups is None or len(groups) <= 1:
+        o = F.scaled_dot_product_attention(q, k, v)
+    else:
+        o = torch.zeros_like(q)  # rows outside every block are fully masked -> nan_to_num -> 0 (:131)
+        for s, t in groups:
+            if t > s:
+                o[:, :, s:t] = F.scaled_dot_product_attention(q[:, :, s:t], k[:, :, s:t], v[:, :, s:t])
+    o = o.transpose(1, 2).reshape(bs, nq, e)
+    return F.linear(o, attn.out_proj.weight, attn.out_proj.bias)
+
+
+@ATTENTION.register_module()
+class MultiheadAttention(BaseModule):
+    """mmcv.cnn.bricks.transformer.MultiheadAttention as the reference configures it
+    (config :167-173,200-215: batch_first=True, legacy `dropout=` kwarg). Eval only: dropouts
+    are kept as modules for structure but are identity at inference."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0.0, proj_drop=0.0,
+                 dropout_layer=dict(type="Dropout", drop_prob=0.0), init_cfg=None, batch_first=False, **kwargs):
+        super().__init__(init_cfg)
+        dropout_layer = dict(dropout_layer) if dropout_layer else None
+        if "dropout" in kwargs:
+            attn_drop = kwargs["dropout"]
+            if dropout_layer is not None:
+                dropout_layer["drop_prob"] = kwargs.pop("dropout")
+            else:
+                kwargs.pop("dropout")
+        self.embed_dims = embed_dims
+        self.num_heads = num_heads
+        self.batch_first = batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.dropout_layer = build_dropout(dropout_layer) if dropout_layer else nn.Identity()
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                key_padding_mask=None, **kwargs):
+        if attn_mask is not None or key_padding_mask is not None:
+            raise NotImplementedError("attention masks only occur on the reference's training path")
+        same_qk = key is None
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        if identity is None:
+            identity = query
+        if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
+            key_pos = query_pos
+        if query_pos is not None:
+            query = query + query_pos
+        if same_qk and key_pos is query_pos:
+            key = query  # q and k share one input: their projections fuse into one GEMM
+        else:
+            same_qk = False
+            if key_pos is not None:
+                key = key + key_pos
+        if not self.batch_first:
+            query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+        out = mha_forward(self.attn, query, key, value, same_qk=same_qk)
+        if not self.batch_first:
+            out = out.transpose(0, 1)
+        return identity + self.dropout_layer(self.proj_drop(out))

@@ -90,3 +90,67 @@ def compare_result(res, g, prefix, box_tol=1e-3, score_tol=1e-3):
     assert tuple(t.shape) == tuple(G("trans_shape").tolist())
     assert np.array_equal(nz, G("trans_nz").astype(np.int64))
     assert np.array_equal(np.asarray(res["query_groups"], np.int64), G("query_groups").astype(np.int64))
+
+
+def _flat(x):
+    if torch.is_tensor(x):
+        return [x]
+    if isinstance(x, (list, tuple)):
+        out = []
+        for y in x:
+            out += _flat(y)
+        return out
+    return []
+
+
+def attach_trace_hooks(head, trace):
+    """Forward hooks on the product head at the same module boundaries the golden generator
+    hooked on the reference head (tools/golden/gen_golden.py:attach_hooks), so records line up
+    by name. The allocation record is taken in index form from `layer.last`."""
+    hooks = []
+    for i, (op, layer) in enumerate(zip(head.operation_order, head.layers)):
+        if layer is None:
+            continue
+        name = f"L{i:02d}.{op}"
+
+        def hook(mod, inp, out, name=name, op=op):
+            if op == "allocation":
+                pts, depth, tmask, tshape = out[:4]
+                a = mod.last
+                trace.add(name + ".ref_pts2d", pts)
+                trace.add(name + ".ref_depth2d", depth)
+                trace.add(name + ".trans_mask", tmask)
+                trace.add(name + ".trans_shape", tshape)
+                trace.add(name + ".q2a", a.q2a)
+                trace.add(name + ".is_center", a.is_center)
+                trace.add(name + ".query_groups", torch.tensor(a.query_groups, dtype=torch.int32))
+            else:
+                for k, t in enumerate(_flat(out)):
+                    trace.add(f"{name}.{k}", t)
+
+        hooks.append(layer.register_forward_hook(hook))
+    for nm in ("anchor_encoder", "anchor_encoder2d", "fc_after", "fc_after2d"):
+        hooks.append(getattr(head, nm).register_forward_hook(lambda m, i, o, nm=nm: trace.add(nm, o)))
+    return hooks
+
+
+def build_product_head(spec, device="cuda"):
+    """The product head for a golden spec: shipped config with the spec's anchor/bank/decoder sizes
+    (the same edits tools/golden/gen_golden.py:build_ref_head makes) and procedural weights."""
+    from simpb_amd import configs, plugin
+    cfg = configs.simpb_plus(anchor=synth.anchors(spec["num_anchor"]))["model"]["head"]
+    cfg["instance_bank"]["num_anchor"] = spec["num_anchor"]
+    cfg["instance_bank"]["num_temp_instances"] = spec["num_temp"]
+    cfg["num_anchor"] = spec["num_anchor"]
+    cfg["decoder"] = dict(type="SparseBox3DDecoder", num_output=spec["num_output"])
+    head = plugin.build_head(cfg).eval()
+    synth.load_procedural(head)
+    return head.to(device)
+
+
+def metas_to(metas, device):
+    out = dict(metas)
+    for k in ("projection_mat", "image_wh", "timestamp"):
+        out[k] = metas[k].to(device)
+    out["image_wh_host"] = tuple(int(v) for v in metas["image_wh"][0, 0].tolist())
+    return out

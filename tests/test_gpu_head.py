@@ -1,0 +1,74 @@
+"""GPU: the whole decoder hot path (product SimPBHead on cuda:0, HIP kernels through the C-ABI)
+against (a) the golden vectors captured from the reference and (b) the oracle run on the same
+inputs on the host. north_star tolerance: boxes/scores within 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+from simpb_amd import synth
+from tests.helpers import (attach_trace_hooks, build_product_head, compare_result, compare_trace, load_golden, metas_to,
+                           spec_of)
+
+pytestmark = pytest.mark.gpu
+
+
+def run_product_stream(g, frames=None):
+    from simpb_amd.plugin import ops
+    spec = spec_of(g)
+    head = build_product_head(spec)
+    with torch.no_grad():
+        for f in range(spec["frames"] if frames is None else frames):
+            trace = synth.Trace()
+            hooks = attach_trace_hooks(head, trace)
+            fm = ops.feature_maps_format([x.cuda() for x in synth.feature_maps_nchw(spec["bs"], f, spec["image_wh"])])
+            metas = metas_to(synth.frame_metas(spec["bs"], f, spec["image_wh"], jump=spec["jump"]), "cuda")
+            outs = head(fm, metas)
+            res = head.post_process(outs, metas)
+            for h in hooks:
+                h.remove()
+            yield f, trace, outs, res, head
+
+
+@pytest.mark.parametrize("name", ["head_small.npz", "head_r50.npz"])
+def test_head_stream_vs_golden(name):
+    g = load_golden(name)
+    spec = spec_of(g)
+    for f, trace, outs, res, head in run_product_stream(g):
+        pre = f"f{f}."
+        assert [x.shape[1] for x in outs["prediction2d"]] == g[pre + "n2#0"].tolist()
+        if f in spec["trace_frames"]:
+            compare_trace(trace, g, pre + "trace.", rtol=1e-3, atol=1e-3)
+        bank = head.instance_bank
+        assert np.allclose(bank.cached_anchor.cpu().numpy(), g[pre + "bank.cached_anchor#0"], atol=1e-3)
+        assert np.array_equal(bank.instance_id.cpu().numpy(), g[pre + "bank.instance_id#0"])
+        assert np.array_equal(outs["instance_id"].cpu().numpy(), g[pre + "instance_id#0"])
+        for b, r in enumerate(res):
+            compare_result(r["img_bbox"], g, f"{pre}res{b}.")
+
+
+def test_head_vs_oracle_other_seed():
+    """Same comparison against the oracle itself on inputs the fixtures do not contain (different
+    weight seed and feature maps), small shapes so the host run takes seconds."""
+    from oracle import simpb_ref as R
+    from simpb_amd.plugin import ops
+    from tests.helpers import golden_params
+    g = load_golden("head_small.npz")
+    spec = spec_of(g)
+    head = build_product_head(spec)
+    synth.load_procedural(head, seed=5)
+    params = {k: v.detach().cpu() for k, v in head.state_dict().items()}
+    oracle = R.OracleHead(params, head.operation_order, spec["num_anchor"], spec["num_temp"], spec["num_output"])
+    with torch.no_grad():
+        for f in range(3):
+            maps = synth.feature_maps_nchw(spec["bs"], f, spec["image_wh"], seed=9)
+            metas = synth.frame_metas(spec["bs"], f, spec["image_wh"])
+            want = oracle.forward(R.feature_maps_format(maps), metas)
+            got = head(ops.feature_maps_format([x.cuda() for x in maps]), metas_to(metas, "cuda"))
+            for k in ("prediction", "classification", "quality", "prediction2d", "classification2d"):
+                for a, b in zip(got[k], want[k]):
+                    if b is None:
+                        assert a is None
+                        continue
+                    assert a.shape == b.shape, k
+                    assert float((a.cpu() - b).abs().max()) <= 1e-3, (k, f)
+            assert torch.equal(got["instance_id"].cpu(), want["instance_id"])
