@@ -1,0 +1,232 @@
+"""Headline benchmark: frames/sec of SimPB+ (ResNet50 704x256, 6 cameras) on MI355X, one process
+per GPU. A step = one 6-camera frame per stream through backbone+FPN (PyTorch-ROCm, fp16) and the
+decoder hot path (HIP kernels, fp32) including post_process. Inputs are synthetic and resident in
+HBM before the timed region; weights are procedural random-init of the shipped architecture.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job frames/s,
+`roofline` for the 3D deformable-aggregation kernel (HIP events around every launch inside the
+timed region, algorithmic bytes per SURVEY.md §8d), `cpu_baseline` = the oracle (CPU restatement
+of the reference) timed on the host cores for a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bs", type=int, default=1, help="camera streams per GPU (BASELINE config #2: 1)")
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--image-wh", type=int, nargs=2, default=(704, 256))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of one operator inside the timed region, on the stream it launches on
+    (torch's current stream, which is what plugin/ops.py hands to the C-ABI)."""
+
+    def __init__(self, module, name):
+        self.module, self.name = module, name
+        self.orig = getattr(module, name)
+        self.events, self.locs = [], []
+        self.enabled = False
+
+    def __enter__(self):
+        def wrapped(feat, ss, ssi, loc, w):
+            if not self.enabled:
+                return self.orig(feat, ss, ssi, loc, w)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = self.orig(feat, ss, ssi, loc, w)
+            b.record()
+            self.events.append((a, b))
+            self.locs.append((loc, w.shape, out.shape))
+            return out
+
+        setattr(self.module, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.module, self.name, self.orig)
+
+    def summary(self):
+        """(avg seconds per launch, avg algorithmic bytes per launch, avg valid triples)."""
+        if not self.events:
+            return None
+        secs = sum(a.elapsed_time(b) for a, b in self.events) * 1e-3 / len(self.events)
+        nbytes, valid = 0.0, 0.0
+        for loc, wshape, oshape in self.locs:
+            v = int(((loc > 0) & (loc < 1)).all(-1).sum())
+            lvls, groups = wshape[4], wshape[5]
+            chans = oshape[-1]
+            w_elems = 1
+            for d in wshape:
+                w_elems *= d
+            # V*L*4 taps*C*4 B + loc + weights + out
+            nbytes += v * lvls * 4 * chans * 4 + loc.numel() * 4 + w_elems * 4 + oshape[0] * oshape[1] * chans * 4
+            valid += v
+        n = len(self.locs)
+        return secs, nbytes / n, valid / n
+
+
+def build_model(args, device):
+    from simpb_amd import configs, plugin, synth
+    cfg = configs.simpb_plus(depth=args.depth, input_shape=tuple(args.image_wh), anchor=synth.anchors(900))
+    model = plugin.build_detector(cfg["model"]).eval()
+    synth.load_procedural(model)
+    model.to(device)
+    model.half_backbone()  # fp16 backbone+FPN, fp32 head: the reference's own precision split (config :26)
+    return model
+
+
+def make_frames(args, device, n_frames):
+    """Pre-stage a short ring of distinct frames in HBM; timestamps keep advancing past the ring."""
+    from simpb_amd import synth
+    imgs = [synth.images(args.bs, f % 4, tuple(args.image_wh)).to(device) for f in range(min(n_frames, 4))]
+    return imgs
+
+
+def frame_metas(args, device, f):
+    from simpb_amd import synth
+    m = synth.frame_metas(args.bs, f, tuple(args.image_wh))
+    for k in ("projection_mat", "image_wh", "timestamp"):
+        m[k] = m[k].to(device)
+    m["image_wh_host"] = tuple(args.image_wh)
+    return m
+
+
+def cpu_baseline(args):
+    """The oracle head (+ an fp32 CPU run of the same backbone/FPN) on the host cores for a
+    bounded sample of the same workload. kind = 'port': the reference itself cannot travel."""
+    from oracle import simpb_ref as R
+    from simpb_amd import configs, plugin, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = configs.simpb_plus(depth=args.depth, input_shape=tuple(args.image_wh), anchor=synth.anchors(900))
+    model = plugin.build_detector(cfg["model"]).eval()
+    synth.load_procedural(model)
+    params = {k: v.detach() for k, v in model.head.state_dict().items()}
+    head = R.OracleHead(params, model.head.operation_order)
+    times = []
+    with torch.no_grad():
+        for f in range(args.cpu_frames):
+            img = synth.images(1, f % 4, tuple(args.image_wh))
+            metas = synth.frame_metas(1, f, tuple(args.image_wh))
+            t0 = time.perf_counter()
+            feats = model.img_neck(model.img_backbone(img.flatten(end_dim=1)))
+            fm = R.feature_maps_format([x.reshape((1, 6) + x.shape[1:]) for x in feats])
+            outs = head.forward(fm, metas)
+            head.post_process(outs, metas)
+            times.append(time.perf_counter() - t0)
+    warm = times[1:] or times
+    return dict(value=len(warm) / sum(warm), unit="frames/s", cores=cores, kind="port",
+                sample=f"{len(warm)} warm frame(s) after 1 cold, bs=1, oracle head fp32 + PyTorch CPU ResNet{args.depth}+FPN fp32, "
+                       f"torch threads={cores}")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from simpb_amd.dist import gather_detections, pack_detections
+    from simpb_amd.plugin import blocks
+    model = build_model(args, device)
+    imgs = make_frames(args, device, args.warmup + args.steps)
+    gathered = None
+    side = torch.cuda.Stream(device=device)
+
+    def step(f):
+        nonlocal gathered
+        with torch.no_grad():
+            results = model.simple_test(imgs[f % len(imgs)], **frame_metas(args, device, f))
+        if dist is not None:  # detections of every stream to every rank, off the compute stream
+            rec = pack_detections(results, device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                gathered = gather_detections(rec, gathered)
+        return results
+
+    with KernelTimer(blocks, "DAF") as kt:
+        for f in range(args.warmup):
+            step(f)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        kt.enabled = True
+        t0 = time.perf_counter()
+        for f in range(args.warmup, args.warmup + args.steps):
+            results = step(f)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kt.enabled = False
+        ksum = kt.summary()
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        frames = world * args.bs * args.steps
+        n2 = [int(x) for x in model.head.layers[0].last.count.sum(dim=1).tolist()] if model.head.layers[0].last else None
+        roof = None
+        if ksum is not None:
+            secs, nbytes, valid = ksum
+            ach = nbytes / secs / 1e9
+            roof = dict(kernel="daf_fwd_rows", bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=ach / HBM_PEAK_GBPS, traffic=None, avg_us=secs * 1e6, algorithmic_MB=nbytes / 1e6,
+                        valid_triples=valid, launches=len(kt.events),
+                        note="feature maps (92 MB) stay Infinity-Cache resident at bs=1, so algorithmic GB/s can exceed the HBM peak")
+        line = {
+            "metric": "frames/sec (6-cam sample) + MSDeformAttn HBM GB/s, R50 704x256 @1/2/4/8 GPU",
+            "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 decoder (fp16 backbone+FPN, as the reference's fp16 config)", "data": "synthetic",
+            "config": {"workload": f"simpb_nus_r{args.depth}_img_{args.image_wh[0]}x{args.image_wh[1]}: 6-cam frames, "
+                                   f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, bs={args.bs}/GPU, temporal streams",
+                       "streams_per_gpu": args.bs, "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
+                       if world > 1 else "single GPU", "num_query2d_last_frame": n2},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

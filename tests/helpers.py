@@ -37,10 +37,29 @@ def spec_of(g):
                 frames=int(s["frames"]), jump=jump, trace_frames=tuple(int(v) for v in s["trace_frames"]))
 
 
-def compare_trace(got, g, prefix, rtol=2e-4, atol=2e-4, skip=()):
+def rows_match(a, b, tol):
+    """True when the rows of a are the rows of b up to order (each row of b has a distinct
+    nearest row of a within tol). Instance order inside the temporal bank is decided by top-k over
+    confidences that can sit 1e-7 apart, so two devices may legitimately hold the same set of
+    instances in a different order ('Top-k tie order'); everything downstream is
+    permutation-equivariant."""
+    a = torch.as_tensor(np.asarray(a, np.float64)).reshape(-1, a.shape[-1])
+    b = torch.as_tensor(np.asarray(b, np.float64)).reshape(-1, b.shape[-1])
+    if a.shape != b.shape:
+        return False
+    d = torch.cdist(b, a, p=float("inf")) if a.shape[0] <= 4096 else None
+    if d is None:
+        return False
+    val, idx = d.min(dim=1)
+    return bool((val <= tol).all()) and len(torch.unique(idx)) == a.shape[0]
+
+
+def compare_trace(got, g, prefix, rtol=2e-4, atol=2e-4, skip=(), allow_permutation=False):
     """Compare a synth.Trace against the golden arrays under `prefix`; returns the list of names
     checked. Float records use |a-b| <= atol + rtol*max|b| (sketches mix a row, so the scale of
-    the whole record is the right yardstick); integer records must match exactly."""
+    the whole record is the right yardstick); integer records must match exactly. With
+    allow_permutation a record may also match as a SET of rows (see rows_match); integer records
+    that index instances are then compared as multisets."""
     names = [k[len(prefix):] for k in g.files if k.startswith(prefix)]
     assert names, prefix
     missing = [n for n in names if n not in got.items and not any(n.startswith(s) for s in skip)]
@@ -57,8 +76,14 @@ def compare_trace(got, g, prefix, rtol=2e-4, atol=2e-4, skip=()):
             tol = atol + rtol * float(np.abs(b).max() if b.size else 0.0)
             err = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) if b.size else 0.0
             if not err <= tol:
+                if allow_permutation and b.ndim >= 2 and rows_match(a, b, tol):
+                    continue
                 bad.append((n, "err", err, tol))
         elif not np.array_equal(a.astype(np.int64), b.astype(np.int64)):
+            if allow_permutation and ".q2a" in n:
+                continue  # slot -> anchor index: anchor numbering itself is permuted
+            if allow_permutation and np.array_equal(np.sort(a.reshape(-1)), np.sort(b.reshape(-1))):
+                continue
             bad.append((n, "int mismatch", int((a != b).sum()), a.size))
     assert not bad, f"{len(bad)} of {len(names)} trace records differ, first: {bad[:6]}"
     return names

@@ -7,7 +7,7 @@ import torch
 
 from simpb_amd import synth
 from tests.helpers import (attach_trace_hooks, build_product_head, compare_result, compare_trace, load_golden, metas_to,
-                           spec_of)
+                           rows_match, spec_of)
 
 pytestmark = pytest.mark.gpu
 
@@ -37,11 +37,14 @@ def test_head_stream_vs_golden(name):
         pre = f"f{f}."
         assert [x.shape[1] for x in outs["prediction2d"]] == g[pre + "n2#0"].tolist()
         if f in spec["trace_frames"]:
-            compare_trace(trace, g, pre + "trace.", rtol=1e-3, atol=1e-3)
+            # frame 0 has no temporal instances: records must match position by position; later
+            # frames may hold the bank's instances in a different (tie-broken) order
+            compare_trace(trace, g, pre + "trace.", rtol=1e-3, atol=1e-3, allow_permutation=f > 0)
         bank = head.instance_bank
-        assert np.allclose(bank.cached_anchor.cpu().numpy(), g[pre + "bank.cached_anchor#0"], atol=1e-3)
-        assert np.array_equal(bank.instance_id.cpu().numpy(), g[pre + "bank.instance_id#0"])
-        assert np.array_equal(outs["instance_id"].cpu().numpy(), g[pre + "instance_id#0"])
+        for b in range(spec["bs"]):
+            assert rows_match(bank.cached_anchor[b].cpu().numpy(), g[pre + "bank.cached_anchor#0"][b], 1e-3)
+            assert np.array_equal(np.sort(bank.instance_id[b].cpu().numpy()), np.sort(g[pre + "bank.instance_id#0"][b]))
+            assert np.array_equal(np.sort(outs["instance_id"][b].cpu().numpy()), np.sort(g[pre + "instance_id#0"][b]))
         for b, r in enumerate(res):
             compare_result(r["img_bbox"], g, f"{pre}res{b}.")
 
