@@ -118,7 +118,8 @@ def cpu_baseline(args):
     bounded sample of the same workload. kind = 'port': the reference itself cannot travel."""
     from oracle import simpb_ref as R
     from simpb_amd import configs, plugin, synth
-    cores = os.cpu_count() or 1
+    # the box's CPU share, not the machine's core count: a one-GPU box is entitled to 16 workers
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     cfg = configs.simpb_plus(depth=args.depth, input_shape=tuple(args.image_wh), anchor=synth.anchors(900))
     model = plugin.build_detector(cfg["model"]).eval()

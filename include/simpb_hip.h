@@ -21,6 +21,9 @@ extern "C" {
 /* Library/ABI version (bumped when a signature changes). */
 int simpb_abi_version(void);
 
+/* Text of the HIP error behind the last SIMPB_ELAUNCH on the calling thread ("" if none). */
+const char* simpb_last_error(void);
+
 /* Replaces `deformable_aggregation(...)` (ops/src/deformable_aggregation.cpp:4-19, launcher
  * ops/src/deformable_aggregation_cuda.cu:265-288, kernel :129-187); same argument order plus the
  * stream. Layouts (deformable_aggregation.cpp:22-28):

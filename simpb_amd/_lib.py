@@ -13,6 +13,7 @@ _F = ctypes.c_float
 
 SIGNATURES = {
     "simpb_abi_version": ([], _I),
+    "simpb_last_error": ([], ctypes.c_char_p),
     "simpb_deformable_aggregation_forward": ([_P] * 6 + [_I] * 8 + [_P], _I),
     "simpb_ms_deform_attn_grouped_forward": ([_P] * 7 + [_I] * 8 + [_P], _I),
     "simpb_alloc_project": ([_P] * 5 + [_I] * 3 + [_F] * 5 + [_P], _I),
@@ -32,6 +33,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB} is missing: build it with `python -m simpb_amd.build` (hipcc --offload-arch=gfx950). "
                 "simpb_amd has no fallback path for its HIP kernels.")
+        # torch first: it brings its own HIP runtime (libamdhip64), and the library must bind to
+        # that one. Loaded the other way round the process ends up with two runtimes and the
+        # kernels launch on one that never saw the device ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB)
         for name, (argtypes, restype) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if include/simpb_hip.h and the .so disagree
@@ -43,4 +48,7 @@ def lib():
 
 def check(status, what):
     if status != 0:
-        raise RuntimeError(f"{what} failed: {ERRORS.get(status, status)}")
+        detail = ""
+        if status == 2:
+            detail = " - " + (lib().simpb_last_error() or b"").decode()
+        raise RuntimeError(f"{what} failed: {ERRORS.get(status, status)}{detail}")

@@ -13,12 +13,24 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for path in sources() + [os.path.join(os.path.dirname(HERE), "include", "simpb_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """Content hash, not mtimes: the snapshot sent to the GPU box does not keep mtimes, and a
+    rebuild there would only repeat the one done here."""
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(os.path.dirname(HERE), "include", "simpb_hip.h")]
-    return any(os.path.getmtime(s) > t for s in deps)
+    return open(STAMP).read().strip() != source_hash()
 
 
 def build_extension(force=False, verbose=False):
@@ -29,6 +41,8 @@ def build_extension(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        f.write(source_hash())
     return LIB
 
 

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include "../../include/simpb_hip.h"
 
+extern "C" int simpb_check_launch(void);
+
 namespace {
 
 // ---- step 1: one thread per (batch, anchor, cam): 9 projected points -> flag, 2D ref, depth
@@ -173,7 +175,8 @@ __global__ void aggregate_kernel(float* __restrict__ out_q, float* __restrict__ 
   }
 }
 
-inline int status() { return hipGetLastError() == hipSuccess ? SIMPB_OK : SIMPB_ELAUNCH; }
+inline int status() { return simpb_check_launch(); }
+inline void clear_stale() { (void)hipGetLastError(); }  // errors left by the caller's earlier runtime calls
 
 }  // namespace
 
@@ -184,6 +187,7 @@ extern "C" int simpb_alloc_project(unsigned char* flag, float* sel_xy, float* de
   if (!flag || !sel_xy || !depth || !anchor || !projection_mat || batch_size <= 0 || num_anchors <= 0 || num_cams <= 0)
     return SIMPB_EINVAL;
   const int n = batch_size * num_anchors * num_cams;
+  clear_stale();
   hipLaunchKernelGGL(alloc_project_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), flag,
                      sel_xy, depth, anchor, projection_mat, batch_size, num_anchors, num_cams, img_w, img_h, limit_w,
                      limit_l, limit_h);
@@ -193,6 +197,7 @@ extern "C" int simpb_alloc_project(unsigned char* flag, float* sel_xy, float* de
 extern "C" int simpb_alloc_compact(int* count, int* order, const unsigned char* flag, int batch_size, int num_anchors,
                                    int num_cams, void* stream) {
   if (!count || !order || !flag || batch_size <= 0 || num_anchors <= 0 || num_cams <= 0) return SIMPB_EINVAL;
+  clear_stale();
   hipLaunchKernelGGL(alloc_compact_kernel, dim3(batch_size * num_cams), dim3(256), 0, static_cast<hipStream_t>(stream),
                      count, order, flag, num_anchors);
   return status();
@@ -206,6 +211,7 @@ extern "C" int simpb_alloc_scatter(float* ref_pts2d, float* ref_depth2d, int* q2
   if (!a2q || !group_start || !count || !order || !flag || !sel_xy || !depth || batch_size <= 0 || num_anchors <= 0 ||
       num_cams <= 0 || num_query < 0)
     return SIMPB_EINVAL;
+  (void)hipGetLastError();  // drop a stale error left by earlier runtime calls of the caller
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t na = (size_t)batch_size * num_anchors * num_cams;
   hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, a2q, -1, na);
@@ -224,6 +230,7 @@ extern "C" int simpb_gather_rows(float* out, const float* src, const int* q2a, i
   if (!out || !src || !q2a || batch_size <= 0 || num_anchors <= 0 || num_query <= 0 || channels <= 0 ||
       channels % 4 != 0 || batch_size > 65535)
     return SIMPB_EINVAL;
+  clear_stale();
   hipLaunchKernelGGL(gather_rows_kernel, dim3(num_query, batch_size), dim3(64), 0, static_cast<hipStream_t>(stream), out,
                      src, q2a, num_anchors, num_query, channels / 4);
   return status();
@@ -236,6 +243,7 @@ extern "C" int simpb_aggregate_2d_to_3d(float* out_q, float* out_pos, const floa
   if (!out_q || !out_pos || !q3d || !pos3d || !q2d || !pos2d || !alpha || !a2q || batch_size <= 0 ||
       num_anchors <= 0 || num_cams <= 0 || num_query <= 0 || channels <= 0 || channels % 4 != 0 || batch_size > 65535)
     return SIMPB_EINVAL;
+  clear_stale();
   hipLaunchKernelGGL(aggregate_kernel, dim3(num_anchors, batch_size), dim3(64), 0, static_cast<hipStream_t>(stream),
                      out_q, out_pos, q3d, pos3d, q2d, pos2d, alpha, a2q, num_anchors, num_cams, num_query,
                      channels / 4);

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include "../../include/simpb_hip.h"
 
+extern "C" int simpb_check_launch(void);
+
 namespace {
 
 constexpr int kWaves = 4;
@@ -174,6 +176,7 @@ extern "C" int simpb_deformable_aggregation_forward(
   if (batch_size <= 0 || num_cams <= 0 || num_feat <= 0 || num_embeds <= 0 || num_scale <= 0 || num_anchors <= 0 ||
       num_pts <= 0 || num_groups <= 0 || num_embeds % num_groups != 0 || batch_size > 65535)
     return SIMPB_EINVAL;
+  (void)hipGetLastError();  // drop a stale error left by earlier runtime calls of the caller
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(num_anchors, batch_size);
   const int gd = num_embeds / num_groups;
@@ -188,7 +191,17 @@ extern "C" int simpb_deformable_aggregation_forward(
                        scale_start_index, sample_location, weights, num_cams, num_feat, num_embeds, num_scale,
                        num_anchors, num_pts, num_groups);
   }
-  return hipGetLastError() == hipSuccess ? SIMPB_OK : SIMPB_ELAUNCH;
+  return simpb_check_launch();
 }
 
 extern "C" int simpb_abi_version(void) { return 1; }
+
+// Text of the last HIP error seen by simpb_check_launch() on this thread ("" if none).
+static thread_local const char* g_last_error = "";
+extern "C" const char* simpb_last_error(void) { return g_last_error; }
+extern "C" int simpb_check_launch(void) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return SIMPB_OK;
+  g_last_error = hipGetErrorString(e);
+  return SIMPB_ELAUNCH;
+}

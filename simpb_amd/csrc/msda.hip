@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include "../../include/simpb_hip.h"
 
+extern "C" int simpb_check_launch(void);
+
 namespace {
 
 constexpr int kWaves = 4;
@@ -120,6 +122,7 @@ extern "C" int simpb_ms_deform_attn_grouped_forward(
   if (batch_size <= 0 || num_cams <= 0 || num_value <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 ||
       num_points <= 0 || num_query <= 0 || batch_size > 65535 || channels % 4 != 0)
     return SIMPB_EINVAL;
+  (void)hipGetLastError();  // drop a stale error left by earlier runtime calls of the caller
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(num_query, batch_size), block(kThreads);
 #define SIMPB_MSDA_LAUNCH(PTS)                                                                                   \
@@ -130,5 +133,5 @@ extern "C" int simpb_ms_deform_attn_grouped_forward(
   else if (num_points == 8) SIMPB_MSDA_LAUNCH(8);
   else SIMPB_MSDA_LAUNCH(0);
 #undef SIMPB_MSDA_LAUNCH
-  return hipGetLastError() == hipSuccess ? SIMPB_OK : SIMPB_ELAUNCH;
+  return simpb_check_launch();
 }

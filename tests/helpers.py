@@ -107,9 +107,14 @@ def compare_result(res, g, prefix, box_tol=1e-3, score_tol=1e-3):
         else:
             err = np.abs(a - b).max() if b.size else 0.0
         assert err <= tol, (k, err, tol)
-    for k in ("labels_3d", "labels_2d", "camidx_2d", "instance_ids"):
+    for k in ("labels_3d", "labels_2d", "camidx_2d"):
         a = np.asarray(res[k].detach().cpu() if torch.is_tensor(res[k]) else res[k]).astype(np.int64)
         assert np.array_equal(a, G(k).astype(np.int64)), k
+    ids = np.asarray(res["instance_ids"].detach().cpu()).astype(np.int64)
+    want_ids = G("instance_ids").astype(np.int64)
+    if not np.array_equal(ids, want_ids):  # same tracks up to a relabelling (see rows_match)
+        pairs = set(zip(ids.tolist(), want_ids.tolist()))
+        assert len(pairs) == len(set(ids.tolist())) == len(set(want_ids.tolist())), "instance ids are not a relabelling"
     t = res["trans_matrix"]
     nz = torch.nonzero(t.detach().cpu()).numpy().astype(np.int64)
     assert tuple(t.shape) == tuple(G("trans_shape").tolist())

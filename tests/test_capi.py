@@ -12,11 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "simpb_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(simpb_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(simpb_\w+)\s*\(", text)))
 
 
 def test_header_symbols_exported():
     build.build_extension()
+    import torch  # noqa: F401  (HIP runtime first, see simpb_amd/_lib.py)
     handle = ctypes.CDLL(build.LIB)
     names = declared_symbols()
     assert "simpb_deformable_aggregation_forward" in names and "simpb_ms_deform_attn_grouped_forward" in names
