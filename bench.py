@@ -39,52 +39,81 @@ def parse():
     return ap.parse_args()
 
 
-class KernelTimer:
-    """HIP-event timing of one operator inside the timed region, on the stream it launches on
-    (torch's current stream, which is what plugin/ops.py hands to the C-ABI)."""
+class KernelMeter:
+    """Roofline leg. Durations come from HIP event pairs the library records on the launch stream
+    directly around each sampler launch (simpb_timing_*, include/simpb_hip.h), for every launch of
+    the timed region. The wrappers here only remember each launch's shapes (and the DAF sampling
+    locations, to count valid triples afterwards) so algorithmic bytes can be computed."""
 
-    def __init__(self, module, name):
-        self.module, self.name = module, name
-        self.orig = getattr(module, name)
-        self.events, self.locs = [], []
+    DAF, MSDA = 1, 2
+
+    def __init__(self, steps):
+        from simpb_amd import _lib
+        from simpb_amd.plugin import blocks, group_attn
+        self.lib = _lib.lib()
+        self.blocks, self.group_attn = blocks, group_attn
+        self.daf_orig, self.msda_orig = blocks.DAF, group_attn.ms_deform_attn_grouped
+        self.daf_calls, self.msda_calls = [], []
         self.enabled = False
+        self.capacity = 8 * steps + 64
+        _lib.check(self.lib.simpb_timing_enable(self.capacity), "simpb_timing_enable")
 
     def __enter__(self):
-        def wrapped(feat, ss, ssi, loc, w):
-            if not self.enabled:
-                return self.orig(feat, ss, ssi, loc, w)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            out = self.orig(feat, ss, ssi, loc, w)
-            b.record()
-            self.events.append((a, b))
-            self.locs.append((loc, w.shape, out.shape))
+        def daf(feat, ss, ssi, loc, w):
+            out = self.daf_orig(feat, ss, ssi, loc, w)
+            if self.enabled:
+                self.daf_calls.append((loc, tuple(w.shape), tuple(out.shape)))
             return out
 
-        setattr(self.module, self.name, wrapped)
+        def msda(value, ss, lsi, loc, aw, qcam):
+            out = self.msda_orig(value, ss, lsi, loc, aw, qcam)
+            if self.enabled:
+                self.msda_calls.append((tuple(loc.shape), value.shape[-1]))
+            return out
+
+        self.blocks.DAF = daf
+        self.group_attn.ms_deform_attn_grouped = msda
         return self
 
     def __exit__(self, *exc):
-        setattr(self.module, self.name, self.orig)
+        self.blocks.DAF, self.group_attn.ms_deform_attn_grouped = self.daf_orig, self.msda_orig
+        self.lib.simpb_timing_enable(0)
+
+    def start(self):
+        self.lib.simpb_timing_reset()
+        self.enabled = True
+
+    def _durations(self, kid):
+        import ctypes
+        buf = (ctypes.c_float * self.capacity)()
+        n = self.lib.simpb_timing_read(kid, buf, self.capacity)
+        return [buf[i] * 1e-3 for i in range(max(n, 0))]
 
     def summary(self):
-        """(avg seconds per launch, avg algorithmic bytes per launch, avg valid triples)."""
-        if not self.events:
-            return None
-        secs = sum(a.elapsed_time(b) for a, b in self.events) * 1e-3 / len(self.events)
-        nbytes, valid = 0.0, 0.0
-        for loc, wshape, oshape in self.locs:
-            v = int(((loc > 0) & (loc < 1)).all(-1).sum())
-            lvls, groups = wshape[4], wshape[5]
-            chans = oshape[-1]
-            w_elems = 1
-            for d in wshape:
-                w_elems *= d
-            # SURVEY.md §8(d): V*L*4 taps*C*4 B + loc + weights + out
-            nbytes += v * lvls * 4 * chans * 4 + loc.numel() * 4 + w_elems * 4 + oshape[0] * oshape[1] * chans * 4
-            valid += v
-        n = len(self.locs)
-        return secs, nbytes / n, valid / n
+        self.enabled = False
+        out = {}
+        d = self._durations(self.DAF)
+        if d and len(d) == len(self.daf_calls):
+            nbytes = valid = 0.0
+            for loc, wshape, oshape in self.daf_calls:
+                v = int(((loc > 0) & (loc < 1)).all(-1).sum())
+                w_elems = 1
+                for k in wshape:
+                    w_elems *= k
+                # SURVEY.md §8(d): V * L levels * 4 taps * C * 4 B + loc + weights + out
+                nbytes += v * wshape[4] * 4 * oshape[-1] * 4 + loc.numel() * 4 + w_elems * 4 + oshape[0] * oshape[1] * oshape[2] * 4
+                valid += v
+            n = len(d)
+            out["daf"] = dict(kernel="daf_fwd_rows", secs=sum(d) / n, nbytes=nbytes / n, launches=n, valid_triples=valid / n)
+        d = self._durations(self.MSDA)
+        if d and len(d) == len(self.msda_calls):
+            nbytes = 0.0
+            for (bs, nq, heads, lvls, pts, _), ch in self.msda_calls:
+                # per query: heads*lvls*pts samples * 4 taps * ch * 4 B + loc + attn + out
+                nbytes += bs * nq * (heads * lvls * pts * 4 * ch * 4 + heads * lvls * pts * 3 * 4 + heads * ch * 4)
+            n = len(d)
+            out["msda"] = dict(kernel="msda_grouped_fwd", secs=sum(d) / n, nbytes=nbytes / n, launches=n)
+        return out
 
 
 def build_model(args, device):
@@ -157,7 +186,6 @@ def main():
     torch.cuda.set_device(device)
 
     from simpb_amd.dist import gather_detections, pack_detections
-    from simpb_amd.plugin import blocks
     model = build_model(args, device)
     imgs = make_frames(args, device, args.warmup + args.steps)
     gathered = None
@@ -174,13 +202,13 @@ def main():
                 gathered = gather_detections(rec, gathered)
         return results
 
-    with KernelTimer(blocks, "DAF") as kt:
+    with KernelMeter(args.steps) as kt:
         for f in range(args.warmup):
             step(f)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        kt.enabled = True
+        kt.start()
         t0 = time.perf_counter()
         for f in range(args.warmup, args.warmup + args.steps):
             results = step(f)
@@ -189,7 +217,6 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        kt.enabled = False
         ksum = kt.summary()
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -200,24 +227,28 @@ def main():
     if rank == 0:
         frames = world * args.bs * args.steps
         n2 = [int(x) for x in model.head.layers[0].last.count.sum(dim=1).tolist()] if model.head.layers[0].last else None
-        roof = None
-        if ksum is not None:
-            secs, nbytes, valid = ksum
-            ach = nbytes / secs / 1e9
-            roof = dict(kernel="daf_fwd_rows", bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBPS, traffic=None, avg_us=secs * 1e6, algorithmic_MB=nbytes / 1e6,
-                        valid_triples=valid, launches=len(kt.events),
-                        note="feature maps (92 MB) stay Infinity-Cache resident at bs=1, so algorithmic GB/s can exceed the HBM peak")
+        def roofline(k, note):
+            ach = k["nbytes"] / k["secs"] / 1e9
+            r = dict(kernel=k["kernel"], bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
+                     frac=ach / HBM_PEAK_GBPS, traffic=None, avg_us=k["secs"] * 1e6, algorithmic_MB=k["nbytes"] / 1e6,
+                     launches=k["launches"], note=note)
+            if "valid_triples" in k:
+                r["valid_triples"] = k["valid_triples"]
+            return r
+
+        roof = roofline(ksum["daf"], "3D deformable aggregation; algorithmic bytes per SURVEY.md 8(d); the 92 MB fp32 "
+                        "feature set fits the 256 MiB Infinity Cache, so rows can be served on-die") if "daf" in ksum else None
+        roof2 = roofline(ksum["msda"], "camera-grouped MSDeformAttn sampling over the value_proj output") if "msda" in ksum else None
         line = {
             "metric": "frames/sec (6-cam sample) + MSDeformAttn HBM GB/s, R50 704x256 @1/2/4/8 GPU",
             "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 decoder (fp16 backbone+FPN, as the reference's fp16 config)", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"simpb_nus_r{args.depth}_img_{args.image_wh[0]}x{args.image_wh[1]}: 6-cam frames, "
                                    f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, bs={args.bs}/GPU, temporal streams",
-                       "streams_per_gpu": args.bs, "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
+                       "streams_per_gpu": args.bs, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
                        if world > 1 else "single GPU", "num_query2d_last_frame": n2},
-            "roofline": roof,
+            "roofline": roof, "roofline_msda": roof2,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

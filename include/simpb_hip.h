@@ -24,6 +24,18 @@ int simpb_abi_version(void);
 /* Text of the HIP error behind the last SIMPB_ELAUNCH on the calling thread ("" if none). */
 const char* simpb_last_error(void);
 
+/* Optional per-launch timing for measurement (bench.py): while enabled, the sampler entry points
+ * record a HIP event pair on their launch stream directly around the kernel launch.
+ *   simpb_timing_enable(n)  allocate n event pairs (0 = disable and free); not thread-safe
+ *   simpb_timing_read(id, ms_out, max_n)  waits for the recorded pairs of kernel `id`, writes their
+ *                           elapsed milliseconds, returns how many (or -1)
+ *   simpb_timing_reset()    forget the recorded pairs, keep the allocation */
+#define SIMPB_KERNEL_DAF 1
+#define SIMPB_KERNEL_MSDA 2
+int simpb_timing_enable(int capacity);
+int simpb_timing_read(int kernel_id, float* ms_out, int max_n);
+void simpb_timing_reset(void);
+
 /* Replaces `deformable_aggregation(...)` (ops/src/deformable_aggregation.cpp:4-19, launcher
  * ops/src/deformable_aggregation_cuda.cu:265-288, kernel :129-187); same argument order plus the
  * stream. Layouts (deformable_aggregation.cpp:22-28):

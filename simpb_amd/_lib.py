@@ -14,6 +14,9 @@ _F = ctypes.c_float
 SIGNATURES = {
     "simpb_abi_version": ([], _I),
     "simpb_last_error": ([], ctypes.c_char_p),
+    "simpb_timing_enable": ([_I], _I),
+    "simpb_timing_read": ([_I, _P, _I], _I),
+    "simpb_timing_reset": ([], None),
     "simpb_deformable_aggregation_forward": ([_P] * 6 + [_I] * 8 + [_P], _I),
     "simpb_ms_deform_attn_grouped_forward": ([_P] * 7 + [_I] * 8 + [_P], _I),
     "simpb_alloc_project": ([_P] * 5 + [_I] * 3 + [_F] * 5 + [_P], _I),

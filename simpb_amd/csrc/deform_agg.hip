@@ -16,6 +16,8 @@
 #include "../../include/simpb_hip.h"
 
 extern "C" int simpb_check_launch(void);
+extern "C" int simpb_timing_begin(int kernel_id, void* stream);
+extern "C" void simpb_timing_end(int slot, void* stream);
 
 namespace {
 
@@ -180,6 +182,7 @@ extern "C" int simpb_deformable_aggregation_forward(
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(num_anchors, batch_size);
   const int gd = num_embeds / num_groups;
+  const int tslot = simpb_timing_begin(SIMPB_KERNEL_DAF, stream);
   const bool fast = num_embeds % 4 == 0 && num_embeds <= 256 && gd % 4 == 0 && num_pts * num_cams <= 128;
   if (fast) {
     hipLaunchKernelGGL(daf_fwd_rows, grid, dim3(kThreads), 0, s, output, mc_ms_feat, spatial_shape, scale_start_index,
@@ -191,10 +194,62 @@ extern "C" int simpb_deformable_aggregation_forward(
                        scale_start_index, sample_location, weights, num_cams, num_feat, num_embeds, num_scale,
                        num_anchors, num_pts, num_groups);
   }
+  simpb_timing_end(tslot, stream);
   return simpb_check_launch();
 }
 
 extern "C" int simpb_abi_version(void) { return 1; }
+
+// ---- optional per-launch HIP-event timing (bench.py's roofline leg). Events are recorded on the
+// launch stream immediately around the kernel launch, inside the same C call, so the interval
+// holds the kernel and not the host's time to get from one Python statement to the next.
+namespace {
+struct TimingSlot { hipEvent_t start, stop; int kernel_id; };
+TimingSlot* g_slots = nullptr;
+int g_capacity = 0, g_used = 0;
+}  // namespace
+
+extern "C" int simpb_timing_enable(int capacity) {
+  if (capacity < 0) return SIMPB_EINVAL;
+  for (int i = 0; i < g_capacity; ++i) { hipEventDestroy(g_slots[i].start); hipEventDestroy(g_slots[i].stop); }
+  delete[] g_slots;
+  g_slots = nullptr; g_capacity = 0; g_used = 0;
+  if (capacity == 0) return SIMPB_OK;
+  g_slots = new TimingSlot[capacity];
+  for (int i = 0; i < capacity; ++i) {
+    if (hipEventCreate(&g_slots[i].start) != hipSuccess || hipEventCreate(&g_slots[i].stop) != hipSuccess) return SIMPB_ELAUNCH;
+    g_slots[i].kernel_id = -1;
+  }
+  g_capacity = capacity;
+  return SIMPB_OK;
+}
+
+extern "C" int simpb_timing_begin(int kernel_id, void* stream) {  // returns slot or -1
+  if (g_used >= g_capacity) return -1;
+  const int i = g_used++;
+  g_slots[i].kernel_id = kernel_id;
+  hipEventRecord(g_slots[i].start, static_cast<hipStream_t>(stream));
+  return i;
+}
+
+extern "C" void simpb_timing_end(int slot, void* stream) {
+  if (slot >= 0 && slot < g_capacity) hipEventRecord(g_slots[slot].stop, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int simpb_timing_read(int kernel_id, float* ms_out, int max_n) {
+  if (!ms_out || max_n < 0) return -1;
+  int n = 0;
+  for (int i = 0; i < g_used && n < max_n; ++i) {
+    if (g_slots[i].kernel_id != kernel_id) continue;
+    float ms = 0.f;
+    if (hipEventSynchronize(g_slots[i].stop) != hipSuccess) return -1;
+    if (hipEventElapsedTime(&ms, g_slots[i].start, g_slots[i].stop) != hipSuccess) return -1;
+    ms_out[n++] = ms;
+  }
+  return n;
+}
+
+extern "C" void simpb_timing_reset(void) { g_used = 0; }
 
 // Text of the last HIP error seen by simpb_check_launch() on this thread ("" if none).
 static thread_local const char* g_last_error = "";

@@ -15,6 +15,8 @@
 #include "../../include/simpb_hip.h"
 
 extern "C" int simpb_check_launch(void);
+extern "C" int simpb_timing_begin(int kernel_id, void* stream);
+extern "C" void simpb_timing_end(int slot, void* stream);
 
 namespace {
 
@@ -125,6 +127,7 @@ extern "C" int simpb_ms_deform_attn_grouped_forward(
   (void)hipGetLastError();  // drop a stale error left by earlier runtime calls of the caller
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(num_query, batch_size), block(kThreads);
+  const int tslot = simpb_timing_begin(SIMPB_KERNEL_MSDA, stream);
 #define SIMPB_MSDA_LAUNCH(PTS)                                                                                   \
   hipLaunchKernelGGL(msda_grouped_fwd<PTS>, grid, block, 0, s, output, value, spatial_shapes, level_start,       \
                      sampling_loc, attn_weight, query_cam, num_cams, num_value, num_heads, channels, num_levels, \
@@ -133,5 +136,6 @@ extern "C" int simpb_ms_deform_attn_grouped_forward(
   else if (num_points == 8) SIMPB_MSDA_LAUNCH(8);
   else SIMPB_MSDA_LAUNCH(0);
 #undef SIMPB_MSDA_LAUNCH
+  simpb_timing_end(tslot, stream);
   return simpb_check_launch();
 }

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "simpb_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(simpb_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|void|const char\*)\s+(simpb_\w+)\s*\(", text)))
 
 
 def test_header_symbols_exported():
