@@ -227,10 +227,21 @@ def main():
     if rank == 0:
         frames = world * args.bs * args.steps
         n2 = [int(x) for x in model.head.layers[0].last.count.sum(dim=1).tolist()] if model.head.layers[0].last else None
+        def pmc_traffic(kernel):
+            """HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside
+            this process); None when no profile of this kernel is committed."""
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sampler_traffic.json")), reverse=True):
+                try:
+                    return json.load(open(path))["kernels"][kernel]["traffic_bytes_per_launch"]
+                except (KeyError, ValueError):
+                    continue
+            return None
+
         def roofline(k, note):
             ach = k["nbytes"] / k["secs"] / 1e9
             r = dict(kernel=k["kernel"], bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
-                     frac=ach / HBM_PEAK_GBPS, traffic=None, avg_us=k["secs"] * 1e6, algorithmic_MB=k["nbytes"] / 1e6,
+                     frac=ach / HBM_PEAK_GBPS, traffic=pmc_traffic(k["kernel"]), avg_us=k["secs"] * 1e6, algorithmic_MB=k["nbytes"] / 1e6,
                      launches=k["launches"], note=note)
             if "valid_triples" in k:
                 r["valid_triples"] = k["valid_triples"]
