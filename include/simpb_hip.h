@@ -89,11 +89,18 @@ int simpb_alloc_project(unsigned char* flag, float* sel_xy, float* depth, const 
 int simpb_alloc_compact(int* count, int* order, const unsigned char* flag, int batch_size, int num_anchors,
                         int num_cams, void* stream);
 
+/* Step 2b, optional (:91-99 without the host round trip): group_start i32 [num_cams + 1] =
+ * prefix sums of the max-over-batch counts, clipped to `capacity`; overflow i32 [1] = 1 when the 2D
+ * query set does not fit `capacity` (the caller must then redo the frame with a larger capacity). */
+int simpb_alloc_group_start(int* group_start, int* overflow, const int* count, int batch_size, int num_cams,
+                            int capacity, void* stream);
+
 /* Step 3 (:103-142): fill the slot tables. group_start i32 [num_cams + 1] (device) are the
  * max-over-batch prefix sums (:91-99); slots past a sample's own count are pads (q2a = -1, zeros).
  *   ref_pts2d f32 [bs, num_query, 2] (divided by img_w, img_h); ref_depth2d f32 [bs, num_query, 1] = |depth|
  *   q2a i32 [bs, num_query] slot -> anchor; is_center i32 [bs, num_query];
  *   a2q i32 [bs, num_anchors, num_cams] (anchor, cam) -> slot or -1; query_cam i32 [num_query]
+ *   (num_query may exceed group_start[num_cams]: those capacity slots get query_cam = -1 and pad values)
  * q2a/is_center are the index form of the reference's one-hot trans_matrix / center_matrix. */
 int simpb_alloc_scatter(float* ref_pts2d, float* ref_depth2d, int* q2a, int* is_center, int* a2q, int* query_cam,
                         const int* group_start, const int* count, const int* order, const unsigned char* flag,

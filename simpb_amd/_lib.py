@@ -21,6 +21,7 @@ SIGNATURES = {
     "simpb_ms_deform_attn_grouped_forward": ([_P] * 7 + [_I] * 8 + [_P], _I),
     "simpb_alloc_project": ([_P] * 5 + [_I] * 3 + [_F] * 5 + [_P], _I),
     "simpb_alloc_compact": ([_P] * 3 + [_I] * 3 + [_P], _I),
+    "simpb_alloc_group_start": ([_P] * 3 + [_I] * 3 + [_P], _I),
     "simpb_alloc_scatter": ([_P] * 12 + [_I] * 4 + [_F] * 2 + [_P], _I),
     "simpb_gather_rows": ([_P] * 3 + [_I] * 4 + [_P], _I),
     "simpb_aggregate_2d_to_3d": ([_P] * 8 + [_I] * 5 + [_P], _I),

@@ -106,11 +106,12 @@ __global__ void alloc_scatter_kernel(float* __restrict__ ref_pts2d, float* __res
   int cam = 0;
   while (cam + 1 < cams && slot >= group_start[cam + 1]) ++cam;
   const int rank = slot - group_start[cam];
-  if (b == 0) query_cam[slot] = cam;
+  const bool in_set = slot < group_start[cams];  // capacity slots past the last group belong to no camera
+  if (b == 0) query_cam[slot] = in_set ? cam : -1;
   const int bc = b * cams + cam;
   float x = 0.f, y = 0.f, d = 0.f;
   int a = -1, ctr = 0;
-  if (rank < count[bc]) {
+  if (in_set && rank < count[bc]) {
     a = order[(size_t)bc * A + rank];
     const size_t o = (size_t)bc * A + a;
     x = sel_xy[2 * o] / img_w;
@@ -124,6 +125,24 @@ __global__ void alloc_scatter_kernel(float* __restrict__ ref_pts2d, float* __res
   ref_depth2d[idx] = d;
   q2a[idx] = a;
   is_center[idx] = ctr;
+}
+
+// ---- device-side group table (allocation.py:91-99 without the .tolist()): group_start[c+1] =
+// sum over c' <= c of max over batch of count[b, c']; overflow[0] = 1 if the set exceeds capacity
+__global__ void alloc_group_start_kernel(int* __restrict__ group_start, int* __restrict__ overflow,
+                                         const int* __restrict__ count, int bs, int cams, int capacity) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int acc = 0;
+  group_start[0] = 0;
+  bool over = false;
+  for (int c = 0; c < cams; ++c) {
+    int m = 0;
+    for (int b = 0; b < bs; ++b) m = max(m, count[b * cams + c]);
+    acc += m;
+    if (acc > capacity) { over = true; acc = capacity; }
+    group_start[c + 1] = acc;
+  }
+  overflow[0] = over ? 1 : 0;
 }
 
 __global__ void fill_int_kernel(int* __restrict__ p, int v, size_t n) {
@@ -200,6 +219,15 @@ extern "C" int simpb_alloc_compact(int* count, int* order, const unsigned char* 
   clear_stale();
   hipLaunchKernelGGL(alloc_compact_kernel, dim3(batch_size * num_cams), dim3(256), 0, static_cast<hipStream_t>(stream),
                      count, order, flag, num_anchors);
+  return status();
+}
+
+extern "C" int simpb_alloc_group_start(int* group_start, int* overflow, const int* count, int batch_size, int num_cams,
+                                       int capacity, void* stream) {
+  if (!group_start || !overflow || !count || batch_size <= 0 || num_cams <= 0 || capacity <= 0) return SIMPB_EINVAL;
+  clear_stale();
+  hipLaunchKernelGGL(alloc_group_start_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), group_start,
+                     overflow, count, batch_size, num_cams, capacity);
   return status();
 }
 

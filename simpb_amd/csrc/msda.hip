@@ -78,7 +78,11 @@ __global__ __launch_bounds__(kThreads) void msda_grouped_fwd(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int HC = heads * ch;
   int cam = query_cam[q];
-  cam = min(max(cam, 0), num_cams - 1);
+  if (cam < 0) {  // capacity slot outside every camera group: defined output, no sampling
+    for (int c = threadIdx.x; c < HC; c += kThreads) out[((size_t)b * nq + q) * HC + c] = 0.f;
+    return;
+  }
+  cam = min(cam, num_cams - 1);
   const float* vcam = value + ((size_t)b * num_cams + cam) * num_value * HC;
   const size_t qrow = (size_t)b * nq + q;
 

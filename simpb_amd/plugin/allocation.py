@@ -15,7 +15,8 @@ class Allocation2D:
     """Index form of one allocation: what the reference spreads over ref_trans_matrix /
     ref_center_matrix / query_groups."""
 
-    __slots__ = ("q2a", "is_center", "a2q", "query_cam", "query_groups", "num_anchor", "count")
+    __slots__ = ("q2a", "is_center", "a2q", "query_cam", "query_groups", "num_anchor", "count", "group_start",
+                 "overflow")
 
     def dense(self):
         """The reference's (trans_matrix, center_matrix) one-hot f32 [bs, N2, N3] (allocation.py:128-142)."""
@@ -40,15 +41,18 @@ class DynamicQueryAllocation(nn.Module):
         self.limit_corners_num = limit_corners_num
         self.last = None
 
-    def forward(self, anchor3d, metas, dense=True):
+    def forward(self, anchor3d, metas, dense=True, capacity=None):
         """Returns the reference's 8-tuple (allocation.py:144). With dense=True the two one-hot
         matrices are materialised from the index form; with dense=False their places hold None
         and callers use `self.last` (an Allocation2D) instead."""
-        alloc, ref_pts2d, ref_depth2d, trans_mask, trans_shape = self.allocate(anchor3d, metas)
+        alloc, ref_pts2d, ref_depth2d, trans_mask, trans_shape = self.allocate(anchor3d, metas, capacity)
         trans, center = alloc.dense() if dense else (None, None)
         return ref_pts2d, ref_depth2d, trans_mask, trans_shape, trans, center, alloc.query_groups, None
 
-    def allocate(self, anchor3d, metas):
+    def allocate(self, anchor3d, metas, capacity=None):
+        """capacity=None: size the 2D set exactly (one count readback, like allocation.py:94).
+        capacity=N: static shapes, no host round trip; the group table stays on the device, slots
+        past the last group carry query_cam = -1, and `overflow` flags a set that did not fit."""
         if self.training:
             raise NotImplementedError("training-time corner sampling (allocation.py:85-87) is not on this path")
         _require_gpu(anchor3d)
@@ -75,12 +79,20 @@ class DynamicQueryAllocation(nn.Module):
         order = torch.empty(bs, cams, num_anchor, dtype=torch.int32, device=dev)
         _lib.check(lib.simpb_alloc_compact(_ptr(count), _ptr(order), _ptr(flag), bs, num_anchor, cams, st),
                    "simpb_alloc_compact")
-        meta = count.max(dim=0).values.tolist()  # the one device->host sync (allocation.py:91-94)
-        cum = [0]
-        for c in meta:
-            cum.append(cum[-1] + int(c))
-        n2 = cum[-1]
-        group_start = torch.tensor(cum, dtype=torch.int32).to(dev, non_blocking=True)
+        overflow = None
+        if capacity is None:
+            meta = count.max(dim=0).values.tolist()  # the one device->host sync (allocation.py:91-94)
+            cum = [0]
+            for c in meta:
+                cum.append(cum[-1] + int(c))
+            n2 = cum[-1]
+            group_start = torch.tensor(cum, dtype=torch.int32).to(dev, non_blocking=True)
+        else:
+            cum, n2 = None, int(capacity)
+            group_start = torch.empty(cams + 1, dtype=torch.int32, device=dev)
+            overflow = torch.empty(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.simpb_alloc_group_start(_ptr(group_start), _ptr(overflow), _ptr(count), bs, cams, n2, st),
+                       "simpb_alloc_group_start")
         ref_pts2d = torch.empty(bs, n2, 2, device=dev)
         ref_depth2d = torch.empty(bs, n2, 1, device=dev)
         out = Allocation2D()
@@ -88,9 +100,11 @@ class DynamicQueryAllocation(nn.Module):
         out.is_center = torch.empty(bs, n2, dtype=torch.int32, device=dev)
         out.a2q = torch.empty(bs, num_anchor, cams, dtype=torch.int32, device=dev)
         out.query_cam = torch.empty(n2, dtype=torch.int32, device=dev)
-        out.query_groups = [(cum[i], cum[i + 1]) for i in range(cams)]
+        out.query_groups = [(cum[i], cum[i + 1]) for i in range(cams)] if cum is not None else None
         out.num_anchor = num_anchor
         out.count = count
+        out.group_start = group_start
+        out.overflow = overflow
         _lib.check(lib.simpb_alloc_scatter(_ptr(ref_pts2d), _ptr(ref_depth2d), _ptr(out.q2a), _ptr(out.is_center),
                                            _ptr(out.a2q), _ptr(out.query_cam), _ptr(group_start), _ptr(count),
                                            _ptr(order), _ptr(flag), _ptr(sel_xy), _ptr(depth), bs, num_anchor, cams, n2,

@@ -228,6 +228,72 @@ class SparseBox3DDecoder(object):
             indices = torch.gather(indices, 1, idx)
         return cls_scores, cls_scores_origin, cls_ids, indices, mask, num_cls
 
+    # ---- static-shape split of decode_with2d: everything with a fixed shape stays on the device
+    # (and inside a captured frame); the variable-length 2D association is finished on the host
+    # from two small fixed-shape records.
+    def decode_static_device(self, cls_scores, box_preds, instance_id, qulity, cls_scores2d, box_preds2d, alloc,
+                             aug_config, output_idx=-1, output_idx2d=-1):
+        """Returns (rec3d f32 [bs, num_output, 14], rec2d f32 [bs, N2cap, 8]):
+        rec3d = 10 decoded box + score + label + pre-centerness score + instance id (decoder.py:133-167, 23-34);
+        rec2d = 4 decoded box + score + label + rank of the slot's anchor in the sorted top-k (or -1)
+        + camera of the slot (or -1)."""
+        scores, origin, cls_ids, indices, mask, num_cls = self._rank(cls_scores, qulity, output_idx, True)
+        if mask is not None:
+            raise NotImplementedError("score_threshold with the static decoder")
+        box = torch.gather(box_preds[output_idx], 1, indices[..., None].expand(-1, -1, box_preds[output_idx].shape[-1]))
+        bs, k, d = box.shape
+        box3d = self.decode_box(box.reshape(bs * k, d)).reshape(bs, k, -1)
+        labels = torch.gather(cls_ids, 1, indices)
+        ids = torch.gather(instance_id, 1, indices)
+        rec3d = torch.cat([box3d, scores[..., None], labels[..., None].to(box3d.dtype), origin[..., None],
+                           ids[..., None].to(box3d.dtype)], dim=-1)
+        q2a = alloc.q2a.long()
+        num_anchor = box_preds[output_idx].shape[1]
+        rank_of_anchor = torch.full((bs, num_anchor + 1), -1, dtype=torch.long, device=q2a.device)
+        rank_of_anchor.scatter_(1, indices, torch.arange(k, device=q2a.device)[None].expand(bs, -1))
+        slot_rank = torch.gather(rank_of_anchor, 1, torch.where(q2a >= 0, q2a, num_anchor))
+        s2d, l2d = cls_scores2d[output_idx2d].sigmoid().max(dim=-1)
+        box2d = self.decode_box2d(box_preds2d[output_idx2d], aug_config)
+        cam = alloc.query_cam[None].expand(bs, -1)
+        rec2d = torch.cat([box2d, s2d[..., None], l2d[..., None].to(box2d.dtype), slot_rank[..., None].to(box2d.dtype),
+                           cam[..., None].to(box2d.dtype)], dim=-1)
+        return rec3d, rec2d
+
+    @staticmethod
+    def decode_static_host(rec3d, rec2d, num_cams=6):
+        """Host half: the reference's per-sample dict (decoder.py:176-251) from the two records."""
+        cam_all = rec2d[0][:, 7].long()
+        query_groups, start = [], 0
+        for c in range(num_cams):  # slots are camera-major: group c = the run of slots with camera c
+            n = int((cam_all == c).sum())
+            query_groups.append((start, start + n))
+            start += n
+        output = []
+        for r3, r2 in zip(rec3d, rec2d):
+            rank = r2[:, 6].long()
+            idx2d = torch.where(rank >= 0)[0]
+            trans_t = torch.zeros(r3.shape[0], len(idx2d))
+            trans_t[rank[idx2d], torch.arange(len(idx2d))] = 1.0
+            camidx_2d, query_groups_new = [], []
+            for cam_idx, qg in enumerate(query_groups):
+                part = torch.where(torch.logical_and(qg[0] <= idx2d, idx2d < qg[1]))[0]
+                if len(part) > 0:
+                    qg_new = (int(part[0]), int(part[-1]) + 1)
+                elif len(query_groups_new) > 0:
+                    qg_new = (query_groups_new[-1][-1], query_groups_new[-1][-1])
+                else:
+                    qg_new = (0, 0)
+                camidx_2d.append(torch.ones(len(part)) * cam_idx)
+                query_groups_new.append(qg_new)
+            query_groups = query_groups_new  # the reference re-binds the loop variable (:216)
+            output.append({
+                "boxes_3d": r3[:, :10], "scores_3d": r3[:, 10], "labels_3d": r3[:, 11].long(),
+                "cls_scores": r3[:, 12], "instance_ids": r3[:, 13].long(),
+                "boxes_2d": r2[idx2d, :4], "scores_2d": r2[idx2d, 4], "labels_2d": r2[idx2d, 5].long(),
+                "camidx_2d": torch.cat(camidx_2d), "trans_matrix": trans_t, "query_groups": query_groups,
+            })
+        return output
+
     def decode(self, cls_scores, box_preds, instance_id=None, qulity=None, output_idx=-1):
         squeeze_cls = instance_id is not None
         cls_scores, origin, cls_ids, indices, mask, num_cls = self._rank(cls_scores, qulity, output_idx, squeeze_cls)

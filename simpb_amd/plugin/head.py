@@ -104,6 +104,10 @@ class SimPBHead(BaseModule):
             self.fc_after2d = nn.Identity()
         self.use_deformable_func = True  # set by SimPB.__init__ in the reference (simpb.py:53)
         self._tables = None
+        # None: size the 2D query set exactly each frame (one count readback, the reference's
+        # behaviour). An int: static shapes with that many 2D slots and no host round trip inside
+        # the frame, which is what lets simpb_amd.runner replay the frame as one hipGraph.
+        self.static_capacity = None
 
     def init_weights(self):
         """simpb_head.py:202-212."""
@@ -177,6 +181,8 @@ class SimPBHead(BaseModule):
         quality, prediction, classification = [], [], []
         prediction2d, classification2d, prediction_alpha2d, prediction_depth2d = [], [], [], []
         ref_pts2d_list, ref_trans_shape_list, ref_trans_matrix_list, ref_query_groups_list = [], [], [], []
+        alloc_list = []
+        cap = self.static_capacity
         temp_attn_instance = instance_feature
         encoder2d_dict, feature_maps = self.prepare2d(feature_maps, metas)
         alloc = None
@@ -191,8 +197,9 @@ class SimPBHead(BaseModule):
             elif op == "allocation":
                 assert self.instance_status == "3d"
                 anchor2d, ref_depth2d, ref_trans_mask, ref_trans_shape, _, _, ref_query_groups, _ = layer(
-                    anchor, metas, dense=False)
+                    anchor, metas, dense=False, capacity=cap)
                 alloc = layer.last
+                group_cam = alloc.query_cam if ref_query_groups is None else None
                 instance_feature = gather_rows(instance_feature, alloc.q2a)  # :438
                 anchor_embed2d = self.anchor_encoder2d(anchor2d)
                 ref_pts2d_list.append(anchor2d[..., :2])
@@ -206,7 +213,8 @@ class SimPBHead(BaseModule):
                 self.instance_status = "3d"
             elif op == "qg_self_attn":
                 instance_feature = self.graph_model2d(i, query=instance_feature, value=instance_feature,
-                                                      query_pos=anchor_embed2d, query_groups=ref_query_groups)
+                                                      query_pos=anchor_embed2d, query_groups=ref_query_groups,
+                                                      query_cam=group_cam)
             elif op == "qg_cross_attn":
                 instance_feature = layer(query=instance_feature, query_pos=anchor_embed2d,
                                          reference_points=anchor2d.unsqueeze(2), query_groups=ref_query_groups,
@@ -221,6 +229,7 @@ class SimPBHead(BaseModule):
                 ref_trans_shape_list.append(ref_trans_shape)
                 ref_trans_matrix_list.append(alloc.q2a)  # index form of ref_trans_matrix
                 ref_query_groups_list.append(ref_query_groups)
+                alloc_list.append(alloc)
             elif op == "gnn":
                 instance_feature = self.graph_model(i, instance_feature, value=instance_feature, query_pos=anchor_embed)
             elif op == "temp_gnn":
@@ -251,6 +260,7 @@ class SimPBHead(BaseModule):
             "prediction_alpha2d": prediction_alpha2d, "prediction_depth2d": prediction_depth2d,
             "ref_pts2d_list": ref_pts2d_list, "ref_trans_shape_list": ref_trans_shape_list,
             "ref_trans_matrix_list": ref_trans_matrix_list, "ref_query_groups_list": ref_query_groups_list,
+            "alloc_list": alloc_list,
         }
         self.instance_bank.cache(instance_feature, anchor, cls, metas, feature_maps)
         output["instance_id"] = self.instance_bank.get_instance_id(cls, anchor, self.decoder.score_threshold)

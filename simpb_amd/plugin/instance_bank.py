@@ -42,6 +42,7 @@ class InstanceBank(nn.Module):
         self.anchor = nn.Parameter(torch.tensor(anchor, dtype=torch.float32), requires_grad=anchor_grad)
         self.instance_feature = nn.Parameter(torch.zeros([self.anchor.shape[0], self.embed_dims]),
                                              requires_grad=feat_grad)
+        self._static = None
         self.reset()
 
     def init_weight(self):
@@ -58,13 +59,53 @@ class InstanceBank(nn.Module):
         self.temp_confidence = None
         self.instance_id = None
         self.prev_id = 0
+        self.has_history = False
+        if getattr(self, "_static", None) is not None:
+            self._static["instance_id"].fill_(-1)
+            self._static["prev_id"].zero_()
+            self.instance_id = self._static["instance_id"]
+            self.prev_id = self._static["prev_id"]
+
+    # ---------------------------------------------------------------- static (graph-replayable) state
+    def enable_static(self, batch_size, device):
+        """Keep the temporal state in persistent device buffers that are updated in place, so a
+        captured frame (hipGraph) reads last frame's state and writes this frame's at fixed
+        addresses. Semantics are unchanged; only where the tensors live."""
+        t, n = self.num_temp_instances, self.num_anchor
+        self._static = dict(
+            cached_feature=torch.zeros(batch_size, t, self.embed_dims, device=device),
+            cached_anchor=torch.zeros(batch_size, t, self.anchor.shape[-1], device=device),
+            confidence=torch.zeros(batch_size, t, device=device),
+            instance_id=torch.full((batch_size, n), -1, dtype=torch.long, device=device),
+            prev_id=torch.zeros((), dtype=torch.long, device=device),
+        )
+        self.reset()
+
+    def _keep(self, name, value):
+        """Bind state `name`: rebinding in the default mode, in-place copy into the persistent
+        buffer in static mode."""
+        st = getattr(self, "_static", None)
+        if st is not None and name in st:
+            st[name].copy_(value)
+            value = st[name]
+        setattr(self, name, value)
 
     def get(self, batch_size, metas=None, dn_metas=None):
         """instance_bank.py:79-119. `expand` instead of `tile`: the learned tables are read-only
         downstream, so no [bs, 900, 256] copy is made."""
         instance_feature = self.instance_feature[None].expand(batch_size, -1, -1)
         anchor = self.anchor[None].expand(batch_size, -1, -1)
-        if self.cached_anchor is not None and batch_size == self.cached_anchor.shape[0]:
+        if self._static is not None and self.has_history and "bank_inputs" in metas:
+            # static mode: T_temp2cur f32[bs,4,4] and the raw time step f32[bs] were prepared by the
+            # caller on the host (they only depend on metadata) and already sit in device buffers
+            T_temp2cur, time_interval = metas["bank_inputs"]
+            self.mask = torch.abs(time_interval) <= self.max_time_interval
+            self.cached_feature = self._static["cached_feature"]
+            self.cached_anchor = self.anchor_handler.anchor_projection(
+                self._static["cached_anchor"], [T_temp2cur], time_intervals=[-time_interval])[0]
+            time_interval = torch.where(torch.logical_and(time_interval != 0, self.mask), time_interval,
+                                        time_interval.new_tensor(self.default_time_interval))
+        elif self.cached_anchor is not None and batch_size == self.cached_anchor.shape[0]:
             history_time = self.metas["timestamp"]
             time_interval = (metas["timestamp"] - history_time).to(dtype=instance_feature.dtype)
             self.mask = torch.abs(time_interval) <= self.max_time_interval
@@ -98,7 +139,7 @@ class InstanceBank(nn.Module):
         instance_feature = torch.where(self.mask[:, None, None], selected_feature, instance_feature)
         anchor = torch.where(self.mask[:, None, None], selected_anchor, anchor)
         if self.instance_id is not None:
-            self.instance_id = torch.where(self.mask[:, None], self.instance_id, self.instance_id.new_tensor(-1))
+            self._keep("instance_id", torch.where(self.mask[:, None], self.instance_id, self.instance_id.new_tensor(-1)))
         return instance_feature, anchor
 
     def cache(self, instance_feature, anchor, confidence, metas=None, feature_maps=None):
@@ -129,7 +170,7 @@ class InstanceBank(nn.Module):
             mask = mask & (confidence >= threshold)
         order = torch.cumsum(mask.flatten().long(), 0).reshape(mask.shape) - 1
         instance_id = torch.where(mask, order + self.prev_id, instance_id)
-        self.prev_id = self.prev_id + mask.sum()
+        self._keep("prev_id", self.prev_id + mask.sum())
         self.update_instance_id(instance_id, confidence)
         return instance_id
 
@@ -140,4 +181,4 @@ class InstanceBank(nn.Module):
         else:
             temp_conf = self.temp_confidence
         instance_id = topk(temp_conf, self.num_temp_instances, instance_id[..., None])[1][0].squeeze(dim=-1)
-        self.instance_id = F.pad(instance_id, (0, self.num_anchor - self.num_temp_instances), value=-1)
+        self._keep("instance_id", F.pad(instance_id, (0, self.num_anchor - self.num_temp_instances), value=-1))

@@ -75,7 +75,7 @@ def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
     return layers
 
 
-def mha_forward(attn, query, key, value, groups=None, same_qk=False):
+def mha_forward(attn, query, key, value, groups=None, same_qk=False, query_cam=None):
     """Arithmetic of torch.nn.MultiheadAttention.forward for batch-first [bs, N, E] inputs, using
     `attn` (an nn.MultiheadAttention) purely as the parameter container so checkpoint keys stay
     `attn.in_proj_weight/in_proj_bias/out_proj.*`.
@@ -99,7 +99,14 @@ def mha_forward(attn, query, key, value, groups=None, same_qk=False):
     q = q.reshape(bs, nq, h, hd).transpose(1, 2)
     k = k.reshape(bs, -1, h, hd).transpose(1, 2)
     v = v.reshape(bs, -1, h, hd).transpose(1, 2)
-    if groups is None or len(groups) <= 1:
+    if query_cam is not None:
+        # static-shape form of the same block structure: the camera id of every slot lives on the
+        # device (-1 = capacity slot outside every group), so the mask is built there and no shape
+        # depends on the per-frame counts. Rows with no admissible key come out NaN -> 0 (:131).
+        same = (query_cam[:, None] == query_cam[None, :]) & (query_cam[:, None] >= 0)
+        mask = torch.zeros(same.shape, dtype=q.dtype, device=q.device).masked_fill_(~same, float("-inf"))
+        o = torch.nan_to_num(F.scaled_dot_product_attention(q, k, v, attn_mask=mask))
+    elif groups is None or len(groups) <= 1:
         o = F.scaled_dot_product_attention(q, k, v)
     else:
         o = torch.zeros_like(q)  # rows outside every block are fully masked -> nan_to_num -> 0 (:131)

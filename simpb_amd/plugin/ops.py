@@ -111,16 +111,30 @@ def feature_maps_format(feature_maps, inverse=False):
                 torch.cat([x[2] for x in formated], dim=0)]
 
     bs, num_cams = feature_maps[0].shape[:2]
-    shapes = [tuple(f.shape[-2:]) for f in feature_maps]
+    shapes = tuple(tuple(f.shape[-2:]) for f in feature_maps)
     col = torch.cat([f.reshape(bs, num_cams, f.shape[2], -1) for f in feature_maps], dim=-1)
     col = col.permute(0, 1, 3, 2).flatten(1, 2)
-    spatial_shape = torch.tensor([shapes] * num_cams, dtype=torch.int64, device=col.device)
-    sizes = [h * w for h, w in shapes] * num_cams
-    starts = [0]
-    for s in sizes[:-1]:
-        starts.append(starts[-1] + s)
-    scale_start_index = torch.tensor(starts, dtype=torch.int64, device=col.device).reshape(num_cams, -1)
+    spatial_shape, scale_start_index = _shape_tables(shapes, num_cams, col.device)
     return [col, spatial_shape, scale_start_index]
+
+
+_table_cache = {}
+
+
+def _shape_tables(shapes, num_cams, device):
+    """(spatial_shape i64[cam, lvl, 2], scale_start_index i64[cam, lvl]) for a pyramid, built once
+    per (shapes, cams, device): the tables are constants of the configuration, and building them
+    per frame would put a host->device copy inside every frame (and inside a graph capture)."""
+    key = (shapes, num_cams, str(device))
+    if key not in _table_cache:
+        spatial_shape = torch.tensor([list(map(list, shapes))] * num_cams, dtype=torch.int64)
+        sizes = [h * w for h, w in shapes] * num_cams
+        starts = [0]
+        for s in sizes[:-1]:
+            starts.append(starts[-1] + s)
+        start = torch.tensor(starts, dtype=torch.int64).reshape(num_cams, -1)
+        _table_cache[key] = (spatial_shape.to(device), start.to(device))
+    return _table_cache[key]
 
 
 def query_cam_from_groups(query_groups, num_query, device):
