@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--bs", type=int, default=1, help="camera streams per GPU (BASELINE config #2: 1)")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--image-wh", type=int, nargs=2, default=(704, 256))
+    ap.add_argument("--capacity", type=int, default=1536, help="static 2D query slots (N2 is ~1.1-1.2k at R50 704x256)")
+    ap.add_argument("--eager", action="store_true", help="do not replay the frame as a hipGraph")
+    ap.add_argument("--meter-frames", type=int, default=8, help="instrumented eager frames for the roofline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
@@ -133,13 +136,10 @@ def make_frames(args, device, n_frames):
     return imgs
 
 
-def frame_metas(args, device, f):
+def frame_metas(args, f):
+    """Host-side metadata of frame f, as the reference's test pipeline collects it (config :349-358)."""
     from simpb_amd import synth
-    m = synth.frame_metas(args.bs, f, tuple(args.image_wh))
-    for k in ("projection_mat", "image_wh", "timestamp"):
-        m[k] = m[k].to(device)
-    m["image_wh_host"] = tuple(args.image_wh)
-    return m
+    return synth.frame_metas(args.bs, f, tuple(args.image_wh))
 
 
 def cpu_baseline(args):
@@ -186,15 +186,19 @@ def main():
     torch.cuda.set_device(device)
 
     from simpb_amd.dist import gather_detections, pack_detections
+    from simpb_amd.runner import FrameRunner
     model = build_model(args, device)
-    imgs = make_frames(args, device, args.warmup + args.steps)
+    total = args.warmup + args.steps + args.meter_frames
+    imgs = make_frames(args, device, total)
+    metas = [frame_metas(args, f) for f in range(total)]  # what a dataloader would hand over
+    runner = FrameRunner(model, args.bs, (args.image_wh[1], args.image_wh[0]), capacity=args.capacity, device=device,
+                         use_graph=not args.eager)
     gathered = None
     side = torch.cuda.Stream(device=device)
 
-    def step(f):
+    def step(f, force_eager=False):
         nonlocal gathered
-        with torch.no_grad():
-            results = model.simple_test(imgs[f % len(imgs)], **frame_metas(args, device, f))
+        results = runner.step(imgs[f % len(imgs)], metas[f], force_eager=force_eager)
         if dist is not None:  # detections of every stream to every rank, off the compute stream
             rec = pack_detections(results, device)
             side.wait_stream(torch.cuda.current_stream())
@@ -202,22 +206,32 @@ def main():
                 gathered = gather_detections(rec, gathered)
         return results
 
-    with KernelMeter(args.steps) as kt:
-        for f in range(args.warmup):
-            step(f)
-        if dist is not None:
-            dist.barrier()
+    for f in range(args.warmup):
+        step(f)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(args.warmup, args.warmup + args.steps):
+        results = step(f)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
         torch.cuda.synchronize()
-        kt.start()
-        t0 = time.perf_counter()
-        for f in range(args.warmup, args.warmup + args.steps):
-            results = step(f)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    # roofline leg: the next frames of the same streams, launched one kernel at a time (no graph) with
+    # a HIP event pair recorded around every sampler launch. Event nodes cannot be read back from
+    # inside a replayed graph, so the timed region above stays uninstrumented; rocprofv3 of this same
+    # command sees both and its per-kernel average is what profiles/ holds.
+    ksum = {}
+    if rank == 0 and args.meter_frames > 0:
+        with KernelMeter(args.meter_frames) as kt:
+            kt.start()
+            for f in range(args.warmup + args.steps, total):
+                step(f, force_eager=True)
             torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        ksum = kt.summary()
+            ksum = kt.summary()
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if dist is not None:
@@ -227,6 +241,7 @@ def main():
     if rank == 0:
         frames = world * args.bs * args.steps
         n2 = [int(x) for x in model.head.layers[0].last.count.sum(dim=1).tolist()] if model.head.layers[0].last else None
+        mode = dict(runner.stats, hipgraph=not args.eager, capacity_2d=args.capacity)
         def pmc_traffic(kernel):
             """HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside
             this process); None when no profile of this kernel is committed."""
@@ -258,7 +273,7 @@ def main():
             "config": {"workload": f"simpb_nus_r{args.depth}_img_{args.image_wh[0]}x{args.image_wh[1]}: 6-cam frames, "
                                    f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, bs={args.bs}/GPU, temporal streams",
                        "streams_per_gpu": args.bs, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
-                       if world > 1 else "single GPU", "num_query2d_last_frame": n2},
+                       if world > 1 else "single GPU", "num_query2d_last_frame": n2, "frame_runner": mode},
             "roofline": roof, "roofline_msda": roof2,
         }
         if world == 1 and not args.no_cpu_baseline:

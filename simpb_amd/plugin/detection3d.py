@@ -6,6 +6,10 @@ import torch.nn as nn
 
 from .box3d import *  # noqa: F401,F403
 from .box3d import COS_YAW, H, L, SIN_YAW, VX, W, X, Y, Z, CNS
+
+# X,Y,Z / W,L,H / SIN,COS are contiguous index runs (core/box3d.py:1): plain slices are used instead
+# of list indexing, which would build an index tensor on the host for every call.
+assert (X, Y, Z, W, L, H, SIN_YAW, COS_YAW) == tuple(range(8))
 from .layers import BaseModule, Linear, Scale, bias_init_with_prob, linear_relu_ln
 from .registry import BBOX_CODERS, PLUGIN_LAYERS, POSITIONAL_ENCODING
 
@@ -36,9 +40,9 @@ class SparseBox3DEncoder(BaseModule):
         self.output_fc = embedding_layer(embed_dims[-1], embed_dims[-1]) if output_fc else None
 
     def forward(self, box_3d):
-        pos_feat = self.pos_fc(box_3d[..., [X, Y, Z]])
-        size_feat = self.size_fc(box_3d[..., [W, L, H]])
-        yaw_feat = self.yaw_fc(box_3d[..., [SIN_YAW, COS_YAW]])
+        pos_feat = self.pos_fc(box_3d[..., X:Z + 1])
+        size_feat = self.size_fc(box_3d[..., W:H + 1])
+        yaw_feat = self.yaw_fc(box_3d[..., SIN_YAW:COS_YAW + 1])
         if self.mode == "add":
             output = pos_feat + size_feat + yaw_feat
         else:
@@ -131,7 +135,7 @@ class SparseBox3DKeyPointsGenerator(BaseModule):
         if T_cur2temp_list is not None or temp_timestamps is not None:
             raise NotImplementedError("temporal key points are not used by the SimPB configs")
         bs, num_anchor = anchor.shape[:2]
-        size = anchor[..., None, [W, L, H]].exp()
+        size = anchor[..., None, W:H + 1].exp()
         key_points = self.fix_scale * size
         if self.num_learnable_pts > 0 and instance_feature is not None:
             learnable_scale = (
@@ -142,7 +146,7 @@ class SparseBox3DKeyPointsGenerator(BaseModule):
         x = cos * key_points[..., 0] - sin * key_points[..., 1]
         y = sin * key_points[..., 0] + cos * key_points[..., 1]
         key_points = torch.stack([x, y, key_points[..., 2]], dim=-1)
-        return key_points + anchor[..., None, [X, Y, Z]]
+        return key_points + anchor[..., None, X:Z + 1]
 
     @staticmethod
     def anchor_projection(anchor, T_src2dst_list, src_timestamp=None, dst_timestamps=None, time_intervals=None):
@@ -153,7 +157,7 @@ class SparseBox3DKeyPointsGenerator(BaseModule):
             vel = anchor[..., VX:]
             vel_dim = vel.shape[-1]
             T_src2dst = torch.unsqueeze(T_src2dst_list[i].to(dtype=anchor.dtype), dim=1)
-            center = anchor[..., [X, Y, Z]]
+            center = anchor[..., X:Z + 1]
             if time_intervals is not None:
                 time_interval = time_intervals[i]
             elif src_timestamp is not None and dst_timestamps is not None:
@@ -163,8 +167,8 @@ class SparseBox3DKeyPointsGenerator(BaseModule):
             if time_interval is not None:
                 center = center - vel * time_interval[:, None, None]
             center = torch.matmul(T_src2dst[..., :3, :3], center[..., None]).squeeze(dim=-1) + T_src2dst[..., :3, 3]
-            size = anchor[..., [W, L, H]]
-            yaw = torch.matmul(T_src2dst[..., :2, :2], anchor[..., [COS_YAW, SIN_YAW], None]).squeeze(-1)
+            size = anchor[..., W:H + 1]
+            yaw = torch.matmul(T_src2dst[..., :2, :2], anchor[..., SIN_YAW:COS_YAW + 1].flip(-1)[..., None]).squeeze(-1)
             vel = torch.matmul(T_src2dst[..., :vel_dim, :vel_dim], vel[..., None]).squeeze(-1)
             dst_anchors.append(torch.cat([center, size, yaw, vel], dim=-1))
         return dst_anchors
@@ -192,7 +196,7 @@ class SparseBox3DDecoder(object):
 
     def decode_box(self, box):
         yaw = torch.atan2(box[:, SIN_YAW], box[:, COS_YAW])
-        return torch.cat([box[:, [X, Y, Z]], box[:, [W, L, H]].exp(), yaw[:, None], box[:, VX:]], dim=-1)
+        return torch.cat([box[:, X:Z + 1], box[:, W:H + 1].exp(), yaw[:, None], box[:, VX:]], dim=-1)
 
     def decode_box2d(self, box, aug_config):
         crop = aug_config["crop"]

@@ -103,8 +103,8 @@ class InstanceBank(nn.Module):
             self.cached_feature = self._static["cached_feature"]
             self.cached_anchor = self.anchor_handler.anchor_projection(
                 self._static["cached_anchor"], [T_temp2cur], time_intervals=[-time_interval])[0]
-            time_interval = torch.where(torch.logical_and(time_interval != 0, self.mask), time_interval,
-                                        time_interval.new_tensor(self.default_time_interval))
+            time_interval = time_interval.masked_fill(
+                ~torch.logical_and(time_interval != 0, self.mask), self.default_time_interval)
         elif self.cached_anchor is not None and batch_size == self.cached_anchor.shape[0]:
             history_time = self.metas["timestamp"]
             time_interval = (metas["timestamp"] - history_time).to(dtype=instance_feature.dtype)
@@ -118,8 +118,8 @@ class InstanceBank(nn.Module):
                     self.cached_anchor, [T_temp2cur], time_intervals=[-time_interval])[0]
             if dn_metas is not None:
                 raise NotImplementedError("denoising anchors only exist in training")
-            time_interval = torch.where(torch.logical_and(time_interval != 0, self.mask), time_interval,
-                                        time_interval.new_tensor(self.default_time_interval))
+            time_interval = time_interval.masked_fill(
+                ~torch.logical_and(time_interval != 0, self.mask), self.default_time_interval)
         else:
             self.reset()
             time_interval = instance_feature.new_tensor([self.default_time_interval] * batch_size)
@@ -139,7 +139,7 @@ class InstanceBank(nn.Module):
         instance_feature = torch.where(self.mask[:, None, None], selected_feature, instance_feature)
         anchor = torch.where(self.mask[:, None, None], selected_anchor, anchor)
         if self.instance_id is not None:
-            self._keep("instance_id", torch.where(self.mask[:, None], self.instance_id, self.instance_id.new_tensor(-1)))
+            self._keep("instance_id", self.instance_id.masked_fill(~self.mask[:, None], -1))
         return instance_feature, anchor
 
     def cache(self, instance_feature, anchor, confidence, metas=None, feature_maps=None):
@@ -155,8 +155,11 @@ class InstanceBank(nn.Module):
             confidence[:, : self.num_temp_instances] = torch.maximum(
                 self.confidence * self.confidence_decay, confidence[:, : self.num_temp_instances])
         self.temp_confidence = confidence
-        self.confidence, (self.cached_feature, self.cached_anchor) = topk(
-            confidence, self.num_temp_instances, instance_feature, anchor)
+        conf, (feat, anc) = topk(confidence, self.num_temp_instances, instance_feature, anchor)
+        self._keep("confidence", conf)
+        self._keep("cached_feature", feat)
+        self._keep("cached_anchor", anc)
+        self.has_history = True
 
     def get_instance_id(self, confidence, anchor=None, threshold=None):
         """instance_bank.py:169-184; new ids are numbered on the device (cumsum over the mask) so

@@ -91,7 +91,7 @@ class FrameRunner:
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
-    def step(self, img, metas):
+    def step(self, img, metas, force_eager=False):
         """One frame for all streams: img f32 [bs, cams, 3, H, W] (device), metas as the reference's
         test pipeline collects them (projection_mat, timestamp, img_metas with T_global/T_global_inv/
         aug_config). Returns the reference's list of {'img_bbox': {...}} (simpb_head.py:1089-1123)."""
@@ -99,12 +99,12 @@ class FrameRunner:
         self._stage(img, metas)
         dmetas = self._device_metas(metas)
         warm = self.prev_metas is not None
-        if warm and self.use_graph and self.graph is None and self.warm_frames >= 1:
+        if warm and self.use_graph and not force_eager and self.graph is None and self.warm_frames >= 1:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.outputs = self._frame(dmetas, aug)
-        if warm and self.graph is not None:
+        if warm and self.graph is not None and not force_eager:
             self.graph.replay()
             rec = self.outputs
             self.stats["replay"] += 1
