@@ -184,6 +184,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    # host-side torch ops in the frame loop are tiny; keep the intra-op pool from oversubscribing
+    # the box's CPU share (a pool sized to the machine's core count stalls frames for tens of ms)
+    torch.set_num_threads(max(1, min(4, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
 
     from simpb_amd.dist import gather_detections, pack_detections
     from simpb_amd.runner import FrameRunner

@@ -265,8 +265,12 @@ class SparseBox3DDecoder(object):
 
     @staticmethod
     def decode_static_host(rec3d, rec2d, num_cams=6):
-        """Host half: the reference's per-sample dict (decoder.py:176-251) from the two records."""
-        cam_all = rec2d[0][:, 7].long()
+        """Host half: the reference's per-sample dict (decoder.py:176-251) from the two records.
+        Plain numpy on purpose: these are a few hundred elements, and CPU tensor ops would wake
+        torch's intra-op thread pool once per call (measured: 50 ms stalls on a shared box)."""
+        import numpy as np
+        rec3d, rec2d = np.asarray(rec3d), np.asarray(rec2d)
+        cam_all = rec2d[0][:, 7].astype(np.int64)
         query_groups, start = [], 0
         for c in range(num_cams):  # slots are camera-major: group c = the run of slots with camera c
             n = int((cam_all == c).sum())
@@ -274,27 +278,28 @@ class SparseBox3DDecoder(object):
             start += n
         output = []
         for r3, r2 in zip(rec3d, rec2d):
-            rank = r2[:, 6].long()
-            idx2d = torch.where(rank >= 0)[0]
-            trans_t = torch.zeros(r3.shape[0], len(idx2d))
-            trans_t[rank[idx2d], torch.arange(len(idx2d))] = 1.0
+            rank = r2[:, 6].astype(np.int64)
+            idx2d = np.nonzero(rank >= 0)[0]
+            trans_t = np.zeros((r3.shape[0], len(idx2d)), np.float32)
+            trans_t[rank[idx2d], np.arange(len(idx2d))] = 1.0
             camidx_2d, query_groups_new = [], []
             for cam_idx, qg in enumerate(query_groups):
-                part = torch.where(torch.logical_and(qg[0] <= idx2d, idx2d < qg[1]))[0]
+                part = np.nonzero((qg[0] <= idx2d) & (idx2d < qg[1]))[0]
                 if len(part) > 0:
                     qg_new = (int(part[0]), int(part[-1]) + 1)
                 elif len(query_groups_new) > 0:
                     qg_new = (query_groups_new[-1][-1], query_groups_new[-1][-1])
                 else:
                     qg_new = (0, 0)
-                camidx_2d.append(torch.ones(len(part)) * cam_idx)
+                camidx_2d.append(np.full(len(part), float(cam_idx), np.float32))
                 query_groups_new.append(qg_new)
             query_groups = query_groups_new  # the reference re-binds the loop variable (:216)
+            t = torch.from_numpy
             output.append({
-                "boxes_3d": r3[:, :10], "scores_3d": r3[:, 10], "labels_3d": r3[:, 11].long(),
-                "cls_scores": r3[:, 12], "instance_ids": r3[:, 13].long(),
-                "boxes_2d": r2[idx2d, :4], "scores_2d": r2[idx2d, 4], "labels_2d": r2[idx2d, 5].long(),
-                "camidx_2d": torch.cat(camidx_2d), "trans_matrix": trans_t, "query_groups": query_groups,
+                "boxes_3d": t(r3[:, :10].copy()), "scores_3d": t(r3[:, 10].copy()), "labels_3d": t(r3[:, 11].astype(np.int64)),
+                "cls_scores": t(r3[:, 12].copy()), "instance_ids": t(r3[:, 13].astype(np.int64)),
+                "boxes_2d": t(r2[idx2d, :4]), "scores_2d": t(r2[idx2d, 4]), "labels_2d": t(r2[idx2d, 5].astype(np.int64)),
+                "camidx_2d": t(np.concatenate(camidx_2d)), "trans_matrix": t(trans_t), "query_groups": query_groups,
             })
         return output
 

@@ -120,5 +120,5 @@ class FrameRunner:
                 "capacity (results of this frame were discarded, not degraded)")
         self.prev_metas = dict(img_metas=metas["img_metas"])
         self.head.instance_bank.metas = self.prev_metas
-        results = SparseBox3DDecoder.decode_static_host(rec3d, rec2d, self.head.num_cams)
+        results = SparseBox3DDecoder.decode_static_host(rec3d.numpy(), rec2d.numpy(), self.head.num_cams)
         return [{"img_bbox": r} for r in results]
