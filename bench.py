@@ -125,6 +125,7 @@ def build_model(args, device):
     model = plugin.build_detector(cfg["model"]).eval()
     synth.load_procedural(model)
     model.to(device)
+    model.fuse_conv_bn()  # the reference's own --fuse-conv-bn inference option (tools/benchmark.py:76-78)
     model.half_backbone()  # fp16 backbone+FPN, fp32 head: the reference's own precision split (config :26)
     return model
 

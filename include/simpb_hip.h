@@ -69,6 +69,52 @@ int simpb_ms_deform_attn_grouped_forward(
     int batch_size, int num_cams, int num_value, int num_heads, int channels,
     int num_levels, int num_points, int num_query, void* stream);
 
+/* y[M, N] = x[M, K] . weight[N, K]^T + bias[N] (bias may be NULL), optional ReLU; exact fp32 on the
+ * f32 matrix cores. Replaces nn.Linear where the reference runs it over every camera token:
+ * value_proj in QueryGroupMultiScaleDeformableAttention.forward (models/group_attn.py:176), and the
+ * other large-M Linear layers of the head. Row-major, K contiguous; K % 32 == 0; x and weight
+ * 16-byte aligned. */
+int simpb_linear_f32(float* y, const float* x, const float* weight, const float* bias, int M, int N, int K,
+                     int relu, void* stream);
+
+/* Fused small-MLP chains: a whole `linear_relu_ln` stack (models/blocks.py:32-43) -- [Linear, ReLU]*,
+ * LayerNorm, ..., optional last Linear and Scale -- in one launch; up to 4 independent chains over
+ * the same rows share it (e.g. the pos/size/yaw/vel branches of SparseBox3DEncoder,
+ * models/detection3d/blocks.py:57-74). The argument block is a plain host struct of device
+ * pointers and sizes. Every width <= 256.
+ *   op LINEAR:    w = weight TRANSPOSED, f32 [in_dim, out_dim]; b = bias [out_dim] or NULL; relu 0/1
+ *   op LAYERNORM: w = gamma, b = beta, f32 [in_dim]; eps 1e-5
+ *   chain input:  IN_ROWS    x f32 rows of in_dim values, row stride ldx (floats); optional second
+ *                            addend x2 (row stride ldx2): input = x + x2
+ *                 IN_SINE2D  x f32 rows holding (x, y) in [0,1] at columns 0,1; the 256-d sine embedding
+ *                            of models/utils.py:40-63 (cat(pos_y, pos_x)) is computed in the kernel
+ *   chain output: out rows of the last width, row stride ldo; out_scale (or NULL) multiplies column-wise
+ *                 (mmcv Scale after the last Linear) */
+#define SIMPB_MLP_MAX_OPS 12
+#define SIMPB_MLP_MAX_CHAINS 4
+#define SIMPB_MLP_LINEAR 0
+#define SIMPB_MLP_LAYERNORM 1
+#define SIMPB_MLP_IN_ROWS 0
+#define SIMPB_MLP_IN_SINE2D 1
+typedef struct simpb_mlp_op {
+  int type, in_dim, out_dim, relu;
+  const float* w;
+  const float* b;
+} simpb_mlp_op;
+typedef struct simpb_mlp_chain {
+  const float* x;
+  const float* x2;
+  float* out;
+  const float* out_scale;
+  int ldx, ldx2, ldo, in_dim, in_mode, n_ops;
+  simpb_mlp_op ops[SIMPB_MLP_MAX_OPS];
+} simpb_mlp_chain;
+typedef struct simpb_mlp_args {
+  int num_rows, num_chains;
+  simpb_mlp_chain chain[SIMPB_MLP_MAX_CHAINS];
+} simpb_mlp_args;
+int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream);
+
 /* Adaptive query allocation, replaces DynamicQueryAllocation.projection_allocation
  * (models/allocation.py:27-144) in three steps; the caller reads `count` back between steps 2
  * and 3 to size the 2D query set (the reference does the same with .tolist() at :94).

@@ -1,0 +1,174 @@
+// Fused small-MLP chains (gfx950): a whole `linear_relu_ln` stack of the reference
+// (/root/reference/projects/mmdet3d_plugin/models/blocks.py:32-43) -- [Linear, ReLU]*, LayerNorm,
+// ..., optional last Linear + Scale -- in ONE launch, with the activations of a row tile living in
+// LDS between layers. Used for the 3D anchor encoder (detection3d/blocks.py:57-74: 4 branches x 4 x
+// [Linear, ReLU, LN] = 48 tiny kernels in the reference, 7 times per frame), the 2D sine encoder
+// (detection2d/blocks.py:48-63 + utils.py:40-63), the refinement heads (detection3d/blocks.py:123-154,
+// detection2d/blocks.py:117-144) and the camera encoder (blocks.py:93-99).
+//
+// These chains are tiny (<= 1.5k rows x 256 wide): the cost in the reference is launch count, not
+// FLOPs, so the kernel is organised for latency, not for the matrix cores: one workgroup = R rows,
+// thread t = output column t, weights are read pre-transposed ([in][out], one coalesced 1-KiB
+// wave-load per k, L2-resident and shared by all workgroups), the row tile is broadcast from LDS.
+// Up to 4 independent chains (e.g. the 4 encoder branches) share a launch through blockIdx.y.
+#include <hip/hip_runtime.h>
+#include "../../include/simpb_hip.h"
+
+extern "C" int simpb_check_launch(void);
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxDim = 256;
+
+template <int R>
+__global__ __launch_bounds__(kThreads) void mlp_chain_kernel(simpb_mlp_args args) {
+  __shared__ float act[2][R][kMaxDim];
+  const simpb_mlp_chain& ch = args.chain[blockIdx.y];
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * R;
+  const int N = args.num_rows;
+
+  // ---- input stage
+  if (ch.in_mode == SIMPB_MLP_IN_SINE2D) {
+    // pos2posemb2d (utils.py:40-63) of a 2-d point: 128 features of y then 128 of x;
+    // feature i of an axis = sin or cos (even / odd i) of coord * 2*pi / 10000^(2*(i/2)/128)
+    for (int idx = tid; idx < R * 256; idx += kThreads) {
+      const int r = idx >> 8, j = idx & 255;
+      const int row = row0 + r;
+      float v = 0.f;
+      if (row < N) {
+        const int axis = j < 128 ? 1 : 0, i = j & 127;
+        const float coord = ch.x[(size_t)row * ch.ldx + axis] * 6.283185307179586f;
+        const float dim_t = powf(10000.f, (float)(2 * (i >> 1)) / 128.f);
+        const float p = coord / dim_t;
+        v = (i & 1) ? cosf(p) : sinf(p);
+      }
+      act[0][r][j] = v;
+    }
+  } else {
+    for (int idx = tid; idx < R * ch.in_dim; idx += kThreads) {
+      const int r = idx / ch.in_dim, k = idx - r * ch.in_dim;
+      const int row = row0 + r;
+      float v = 0.f;
+      if (row < N) {
+        v = ch.x[(size_t)row * ch.ldx + k];
+        if (ch.x2) v += ch.x2[(size_t)row * ch.ldx2 + k];
+      }
+      act[0][r][k] = v;
+    }
+  }
+  __syncthreads();
+
+  int cur = 0;
+  int width = ch.in_mode == SIMPB_MLP_IN_SINE2D ? 256 : ch.in_dim;
+  for (int o = 0; o < ch.n_ops; ++o) {
+    const simpb_mlp_op& op = ch.ops[o];
+    if (op.type == SIMPB_MLP_LINEAR) {
+      const int K = op.in_dim, D = op.out_dim;
+      if (tid < D) {
+        float acc[R];
+        const float b = op.b ? op.b[tid] : 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = b;
+        const float* wt = op.w + tid;  // W^T [K][D]
+        int k = 0;
+        for (; k + 4 <= K; k += 4) {
+          const float w0 = wt[(size_t)(k + 0) * D], w1 = wt[(size_t)(k + 1) * D];
+          const float w2 = wt[(size_t)(k + 2) * D], w3 = wt[(size_t)(k + 3) * D];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float4 a = *reinterpret_cast<const float4*>(&act[cur][r][k]);
+            acc[r] = fmaf(a.x, w0, acc[r]);
+            acc[r] = fmaf(a.y, w1, acc[r]);
+            acc[r] = fmaf(a.z, w2, acc[r]);
+            acc[r] = fmaf(a.w, w3, acc[r]);
+          }
+        }
+        for (; k < K; ++k) {
+          const float w0 = wt[(size_t)k * D];
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r] = fmaf(act[cur][r][k], w0, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) act[cur ^ 1][r][tid] = op.relu ? fmaxf(acc[r], 0.f) : acc[r];
+      }
+      __syncthreads();
+      cur ^= 1;
+      width = D;
+    } else {  // LayerNorm over `width` (= op.in_dim), eps 1e-5, biased variance (torch.nn.LayerNorm)
+      const int D = op.in_dim;
+      const int lane = tid & 63, wave = tid >> 6;
+      for (int r = wave; r < R; r += kThreads / 64) {
+        float v[kMaxDim / 64];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxDim / 64; ++j) {
+          const int e = lane + 64 * j;
+          v[j] = e < D ? act[cur][r][e] : 0.f;
+          s += v[j];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        const float mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxDim / 64; ++j) {
+          const int e = lane + 64 * j;
+          const float d = e < D ? v[j] - mean : 0.f;
+          q += d * d;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+        const float inv = 1.f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < kMaxDim / 64; ++j) {
+          const int e = lane + 64 * j;
+          if (e < D) act[cur][r][e] = (v[j] - mean) * inv * op.w[e] + op.b[e];
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- output stage
+  for (int idx = tid; idx < R * width; idx += kThreads) {
+    const int r = idx / width, t = idx - r * width;
+    const int row = row0 + r;
+    if (row < N) {
+      float v = act[cur][r][t];
+      if (ch.out_scale) v *= ch.out_scale[t];
+      ch.out[(size_t)row * ch.ldo + t] = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream) {
+  if (!args || args->num_rows <= 0 || args->num_chains <= 0 || args->num_chains > SIMPB_MLP_MAX_CHAINS)
+    return SIMPB_EINVAL;
+  for (int c = 0; c < args->num_chains; ++c) {
+    const simpb_mlp_chain& ch = args->chain[c];
+    if (!ch.x || !ch.out || ch.n_ops < 0 || ch.n_ops > SIMPB_MLP_MAX_OPS) return SIMPB_EINVAL;
+    int width = ch.in_mode == SIMPB_MLP_IN_SINE2D ? 256 : ch.in_dim;
+    if (width <= 0 || width > kMaxDim) return SIMPB_EINVAL;
+    if (ch.in_mode == SIMPB_MLP_IN_SINE2D && ch.ldx < 2) return SIMPB_EINVAL;
+    for (int o = 0; o < ch.n_ops; ++o) {
+      const simpb_mlp_op& op = ch.ops[o];
+      if (op.type == SIMPB_MLP_LINEAR) {
+        if (!op.w || op.in_dim != width || op.out_dim <= 0 || op.out_dim > kMaxDim) return SIMPB_EINVAL;
+        width = op.out_dim;
+      } else if (op.type == SIMPB_MLP_LAYERNORM) {
+        if (!op.w || !op.b || op.in_dim != width) return SIMPB_EINVAL;
+      } else {
+        return SIMPB_EINVAL;
+      }
+    }
+  }
+  (void)hipGetLastError();
+  constexpr int R = 8;
+  dim3 grid((args->num_rows + R - 1) / R, args->num_chains);
+  hipLaunchKernelGGL(mlp_chain_kernel<R>, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream), *args);
+  return simpb_check_launch();
+}

@@ -80,7 +80,12 @@ class DeformableFeatureAggregation(BaseModule):
         bs, num_anchor = instance_feature.shape[:2]
         feature = instance_feature + anchor_embed
         if self.camera_encoder is not None:
-            camera_embed = self.camera_encoder(metas["projection_mat"][:, :, :3].reshape(bs, self.num_cams, -1))
+            cam_in = metas["projection_mat"][:, :, :3].reshape(bs, self.num_cams, -1)
+            if cam_in.is_cuda:
+                from . import fused
+                camera_embed = fused.chain_forward(self.camera_encoder, cam_in)
+            else:
+                camera_embed = self.camera_encoder(cam_in)
             feature = feature[:, :, None] + camera_embed[:, None]
         weights = (
             self.weights_fc(feature)

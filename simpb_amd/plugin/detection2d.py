@@ -64,6 +64,9 @@ class SparseBox2DEncoder(BaseModule):
 
     def forward(self, box_2d):
         if self.with_sin_embed:
+            if box_2d.is_cuda and box_2d.shape[-1] == 2:
+                from . import fused  # sine embedding + the two Linear/ReLU/LN stages in one launch
+                return fused.chain_forward(self.query_embeddings2d, box_2d, sine=True)
             return self.query_embeddings2d(pos2posemb2d(box_2d))
         pos_feat = self.pos_fc(box_2d[..., :2])
         if not self.with_size:
@@ -102,11 +105,35 @@ class SparseBox2DRefinementModule(BaseModule):
             nn.init.constant_(self.cls_layers[-1].bias, bias_init_with_prob(0.01))
 
     def forward(self, instance_feature, anchor2d, anchor2d_embed, metas=None, return_cls=True, query_groups=None):
-        output = self.layers(instance_feature + anchor2d_embed)
+        fused_ok = instance_feature.is_cuda
+        if fused_ok:
+            from . import fused
+            xf, ldx = fused._rows(instance_feature, instance_feature.shape[-1])
+            ef, lde = fused._rows(anchor2d_embed, anchor2d_embed.shape[-1])
+            n, lead = xf.shape[0], instance_feature.shape[:-1]
+            out_t = torch.empty(n, self.output_dim, device=xf.device)
+            jobs = [dict(plan=fused.plan_of(self.layers), x=(xf, ldx, 0), x2=(ef, lde, 0), out=(out_t, self.output_dim, 0))]
+            cls_t = alpha_t = None
+            if return_cls:
+                cls_t = torch.empty(n, self.num_cls, device=xf.device)
+                jobs.append(dict(plan=fused.plan_of(self.cls_layers), x=(xf, ldx, 0), out=(cls_t, self.num_cls, 0)))
+            if self.with_alpha_branch:
+                adim = fused.plan_of(self.alpha_layers).out_dim
+                alpha_t = torch.empty(n, adim, device=xf.device)
+                jobs.append(dict(plan=fused.plan_of(self.alpha_layers), x=(xf, ldx, 0), out=(alpha_t, adim, 0)))
+            if n:
+                fused.run_chains(jobs, n, xf.device)
+            output = out_t.reshape(lead + (self.output_dim,))
+        else:
+            output = self.layers(instance_feature + anchor2d_embed)
         k = anchor2d.shape[-1]
         if k not in (2, 4):
             raise ValueError(k)
         output = torch.cat([output[..., :k] + inverse_sigmoid(anchor2d), output[..., k:]], dim=-1)  # :122-125
-        cls = self.cls_layers(instance_feature) if return_cls else None
-        alpha = self.alpha_layers(instance_feature) if self.with_alpha_branch else None
+        if fused_ok:
+            cls = cls_t.reshape(lead + (self.num_cls,)) if cls_t is not None else None
+            alpha = alpha_t.reshape(lead + (alpha_t.shape[-1],)) if alpha_t is not None else None
+        else:
+            cls = self.cls_layers(instance_feature) if return_cls else None
+            alpha = self.alpha_layers(instance_feature) if self.with_alpha_branch else None
         return output.sigmoid(), cls, None, alpha

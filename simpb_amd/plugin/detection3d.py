@@ -40,6 +40,8 @@ class SparseBox3DEncoder(BaseModule):
         self.output_fc = embedding_layer(embed_dims[-1], embed_dims[-1]) if output_fc else None
 
     def forward(self, box_3d):
+        if box_3d.is_cuda and self.mode == "cat" and self.output_fc is None and self.vel_dims > 0:
+            return self._forward_fused(box_3d)
         pos_feat = self.pos_fc(box_3d[..., X:Z + 1])
         size_feat = self.size_fc(box_3d[..., W:H + 1])
         yaw_feat = self.yaw_fc(box_3d[..., SIN_YAW:COS_YAW + 1])
@@ -53,6 +55,25 @@ class SparseBox3DEncoder(BaseModule):
         if self.output_fc is not None:
             output = self.output_fc(output)
         return output
+
+
+    def _forward_fused(self, box_3d):
+        """The 4 branches (48 Linear/ReLU/LN modules) as ONE mlp_chain launch: each branch reads its
+        columns of the anchor rows and writes its slice of the concatenated embedding."""
+        from . import fused
+        box = box_3d if box_3d.dtype == torch.float32 and box_3d.is_contiguous() else box_3d.float().contiguous()
+        rows = box.reshape(-1, box.shape[-1])
+        n, ld = rows.shape
+        branches = [(self.pos_fc, X), (self.size_fc, W), (self.yaw_fc, SIN_YAW), (self.vel_fc, VX)]
+        widths = [fused.plan_of(seq).out_dim for seq, _ in branches]
+        out = torch.empty(n, sum(widths), device=box.device, dtype=torch.float32)
+        jobs, col = [], 0
+        for (seq, xcol), wdt in zip(branches, widths):
+            jobs.append(dict(plan=fused.plan_of(seq), x=(rows, ld, xcol), out=(out, out.shape[1], col)))
+            col += wdt
+        if n:
+            fused.run_chains(jobs, n, box.device)
+        return out.reshape(box_3d.shape[:-1] + (out.shape[1],))
 
 
 @PLUGIN_LAYERS.register_module()
@@ -84,8 +105,13 @@ class SparseBox3DRefinementModule(BaseModule):
             nn.init.constant_(self.cls_layers[-1].bias, bias_init_with_prob(0.01))
 
     def forward(self, instance_feature, anchor, anchor_embed, time_interval=1.0, return_cls=True):
-        feature = instance_feature + anchor_embed
-        output = self.layers(feature)
+        fused_ok = instance_feature.is_cuda
+        if fused_ok:
+            from . import fused
+            output = fused.chain_forward(self.layers, instance_feature, anchor_embed)
+        else:
+            feature = instance_feature + anchor_embed
+            output = self.layers(feature)
         # :133 adds the anchor on the refined states; written as one add of a masked anchor so no
         # advanced-index scatter is launched (refine_state is a prefix 0..5 or 0..7)
         n_ref = len(self.refine_state)
@@ -103,11 +129,30 @@ class SparseBox3DRefinementModule(BaseModule):
         output = torch.cat(parts, dim=-1)
         if return_cls:
             assert self.with_cls_branch, "Without classification layers !!!"
+            if fused_ok:
+                cls, quality = self._heads_fused(instance_feature, anchor_embed)
+                return output, cls, quality
             cls = self.cls_layers(instance_feature)
         else:
             cls = None
         quality = self.quality_layers(feature) if return_cls and self.with_quality_estimation else None
         return output, cls, quality
+
+    def _heads_fused(self, instance_feature, anchor_embed):
+        """cls_layers(feature) and quality_layers(feature + embed) (:145-152) in one launch."""
+        from . import fused
+        xf, ldx = fused._rows(instance_feature, instance_feature.shape[-1])
+        ef, lde = fused._rows(anchor_embed, anchor_embed.shape[-1])
+        n = xf.shape[0]
+        lead = instance_feature.shape[:-1]
+        cls = torch.empty(n, self.num_cls, device=xf.device)
+        jobs = [dict(plan=fused.plan_of(self.cls_layers), x=(xf, ldx, 0), out=(cls, self.num_cls, 0))]
+        quality = None
+        if self.with_quality_estimation:
+            quality = torch.empty(n, 2, device=xf.device)
+            jobs.append(dict(plan=fused.plan_of(self.quality_layers), x=(xf, ldx, 0), x2=(ef, lde, 0), out=(quality, 2, 0)))
+        fused.run_chains(jobs, n, xf.device)
+        return cls.reshape(lead + (self.num_cls,)), (quality.reshape(lead + (2,)) if quality is not None else None)
 
 
 @PLUGIN_LAYERS.register_module()

@@ -145,6 +145,31 @@ class SimPB(BaseModule):
         self.depth_branch = build_from_cfg(depth_branch, PLUGIN_LAYERS) if depth_branch is not None else None
         self.fp16_enabled = False
 
+    def fuse_conv_bn(self):
+        """tools/fuse_conv_bn.py:10-48 of the reference (its --fuse-conv-bn benchmark option): fold
+        every eval-mode BatchNorm of the backbone into the convolution in front of it. Done in
+        fp32, before any cast; the BatchNorm modules become Identity."""
+        def fold(conv, bn):
+            w = conv.weight
+            b = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+            factor = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            conv.weight = nn.Parameter(w * factor.reshape(-1, 1, 1, 1))
+            conv.bias = nn.Parameter((b - bn.running_mean) * factor + bn.bias)
+
+        bb = self.img_backbone
+        with torch.no_grad():
+            fold(bb.conv1, bb.bn1)
+            bb.bn1 = nn.Identity()
+            for name in bb.res_layers:
+                for blk in getattr(bb, name):
+                    for i in (1, 2, 3):
+                        fold(getattr(blk, f"conv{i}"), getattr(blk, f"bn{i}"))
+                        setattr(blk, f"bn{i}", nn.Identity())
+                    if blk.downsample is not None:
+                        fold(blk.downsample[0], blk.downsample[1])
+                        blk.downsample[1] = nn.Identity()
+        return self
+
     def half_backbone(self):
         """wrap_fp16_model (tools/test.py:239-241) + @auto_fp16(apply_to=('img',), out_fp32=True)
         (simpb.py:63): backbone and neck in fp16, everything after in fp32. channels_last so the

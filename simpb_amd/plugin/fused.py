@@ -1,0 +1,154 @@
+"""Host side of csrc/mlp_chain.hip: turns the reference's nn.Sequential stacks ([Linear, ReLU]*,
+LayerNorm, ..., Linear, Scale) into the argument block of simpb_mlp_chain_forward. The module tree
+(and so the state_dict) is untouched; the kernel reads the Linear weights through transposed
+copies that are refreshed whenever a parameter is replaced or modified in place."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .layers import Scale
+from .ops import _stream
+
+MAX_OPS, MAX_CHAINS = 12, 4
+LINEAR, LAYERNORM = 0, 1
+IN_ROWS, IN_SINE2D = 0, 1
+
+
+class _Op(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int), ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int), ("relu", ctypes.c_int),
+                ("w", ctypes.c_void_p), ("b", ctypes.c_void_p)]
+
+
+class _Chain(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("x2", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("out_scale", ctypes.c_void_p), ("ldx", ctypes.c_int), ("ldx2", ctypes.c_int), ("ldo", ctypes.c_int),
+                ("in_dim", ctypes.c_int), ("in_mode", ctypes.c_int), ("n_ops", ctypes.c_int), ("ops", _Op * MAX_OPS)]
+
+
+class _Args(ctypes.Structure):
+    _fields_ = [("num_rows", ctypes.c_int), ("num_chains", ctypes.c_int), ("chain", _Chain * MAX_CHAINS)]
+
+
+class ChainPlan:
+    """One nn.Sequential parsed into kernel ops. Holds the transposed weights."""
+
+    def __init__(self, seq):
+        self.seq = seq
+        self.ops = []  # (type, in, out, relu, w_tensor_getter, b_tensor_getter)
+        self.scale = None
+        self._wt = {}
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                self.ops.append((LINEAR, m.in_features, m.out_features, int(relu), m))
+                i += 2 if relu else 1
+            elif isinstance(m, nn.LayerNorm):
+                if len(m.normalized_shape) != 1 or abs(m.eps - 1e-5) > 1e-12:
+                    raise ValueError("unsupported LayerNorm")
+                self.ops.append((LAYERNORM, m.normalized_shape[0], m.normalized_shape[0], 0, m))
+                i += 1
+            elif isinstance(m, Scale) and i == len(mods) - 1:
+                self.scale = m
+                i += 1
+            else:
+                raise ValueError(f"mlp_chain cannot express {type(m).__name__}")
+        if len(self.ops) > MAX_OPS or any(o[1] > 256 or o[2] > 256 for o in self.ops):
+            raise ValueError("chain too long or too wide for mlp_chain")
+        self.in_dim = self.ops[0][1]
+        self.out_dim = self.ops[-1][2]
+
+    def _transposed(self, lin):
+        key = id(lin)
+        w = lin.weight
+        tag = (w.data_ptr(), w._version, w.device)
+        hit = self._wt.get(key)
+        if hit is None or hit[0] != tag:
+            hit = (tag, w.detach().t().contiguous().float())
+            self._wt[key] = hit
+        return hit[1]
+
+    def fill(self, chain, keep):
+        chain.n_ops = len(self.ops)
+        for j, (typ, din, dout, relu, m) in enumerate(self.ops):
+            op = chain.ops[j]
+            op.type, op.in_dim, op.out_dim, op.relu = typ, din, dout, relu
+            if typ == LINEAR:
+                wt = self._transposed(m)
+                keep.append(wt)
+                op.w = wt.data_ptr()
+                op.b = m.bias.data_ptr() if m.bias is not None else None
+            else:
+                op.w, op.b = m.weight.data_ptr(), m.bias.data_ptr()
+        chain.out_scale = self.scale.scale.data_ptr() if self.scale is not None else None
+
+
+def plan_of(seq):
+    plan = getattr(seq, "_simpb_plan", None)
+    if plan is None:
+        plan = ChainPlan(seq)
+        object.__setattr__(seq, "_simpb_plan", plan)
+    return plan
+
+
+def _rows(t, width):
+    """(pointer-ready tensor, row stride) for a [..., width] tensor whose rows are `width`
+    contiguous floats at a constant stride."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    flat = t.reshape(-1, t.shape[-1]) if t.is_contiguous() else None
+    if flat is None:
+        t = t.contiguous()
+        flat = t.reshape(-1, t.shape[-1])
+    return flat, flat.stride(0)
+
+
+def run_chains(jobs, num_rows, device):
+    """jobs: list of dicts(plan, x=(tensor2d, ld, col), x2=(tensor2d, ld, col) or None, out=(tensor2d, ld, col),
+    sine=bool). All tensors f32 on `device`, 2-D views with unit inner stride."""
+    if not jobs or len(jobs) > MAX_CHAINS:
+        raise ValueError("1..4 chains per launch")
+    args = _Args()
+    args.num_rows, args.num_chains = int(num_rows), len(jobs)
+    keep = []
+    for c, job in enumerate(jobs):
+        ch = args.chain[c]
+        plan = job["plan"]
+        xt, ldx, xcol = job["x"]
+        ch.x = xt.data_ptr() + 4 * xcol
+        ch.ldx = ldx
+        if job.get("x2") is not None:
+            x2t, ldx2, x2col = job["x2"]
+            ch.x2, ch.ldx2 = x2t.data_ptr() + 4 * x2col, ldx2
+        else:
+            ch.x2, ch.ldx2 = None, 0
+        ot, ldo, ocol = job["out"]
+        ch.out, ch.ldo = ot.data_ptr() + 4 * ocol, ldo
+        ch.in_mode = IN_SINE2D if job.get("sine") else IN_ROWS
+        ch.in_dim = plan.in_dim
+        plan.fill(ch, keep)
+        keep += [xt, ot]
+    status = _lib.lib().simpb_mlp_chain_forward(ctypes.byref(args), _stream())
+    _lib.check(status, "simpb_mlp_chain_forward")
+
+
+def chain_forward(seq, x, x2=None, sine=False):
+    """y = seq(x + x2) for x [..., in_dim] on the GPU, one launch."""
+    plan = plan_of(seq)
+    xf, ldx = _rows(x, x.shape[-1])
+    job = dict(plan=plan, x=(xf, ldx, 0), sine=sine)
+    if x2 is not None:
+        x2f, ldx2 = _rows(x2, x2.shape[-1])
+        job["x2"] = (x2f, ldx2, 0)
+    n = xf.shape[0]
+    out = torch.empty(n, plan.out_dim, device=x.device, dtype=torch.float32)
+    job["out"] = (out, plan.out_dim, 0)
+    if n:
+        run_chains([job], n, x.device)
+    return out.reshape(x.shape[:-1] + (plan.out_dim,))

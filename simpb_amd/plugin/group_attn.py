@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from .layers import BaseModule, build_dropout, mha_forward
-from .ops import ms_deform_attn_grouped, query_cam_from_groups
+from .ops import linear_f32, ms_deform_attn_grouped, query_cam_from_groups
 from .registry import ATTENTION
 
 
@@ -96,7 +96,7 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
 
     def project_value(self, value, key_padding_mask=None):
         """value_proj over every camera token (:176-179): the largest GEMM of the decoder."""
-        value = self.value_proj(value)
+        value = linear_f32(value, self.value_proj.weight, self.value_proj.bias)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         return value

@@ -178,3 +178,28 @@ def ms_deform_attn_grouped(value, spatial_shapes, level_start_index, sampling_lo
         _ptr(attention_weights), _ptr(query_cam), bs, num_cams, num_value, heads, ch, lvls, pts, nq, _stream())
     _lib.check(status, "simpb_ms_deform_attn_grouped_forward")
     return output
+
+
+def linear_f32(x, weight, bias=None, relu=False):
+    """F.linear(x, weight, bias) (optionally + ReLU) in exact fp32 on the f32 matrix cores
+    (csrc/linear.hip). x [..., K], weight [N, K]; K must be a multiple of 32."""
+    _require_gpu(x, weight)
+    k = x.shape[-1]
+    n = weight.shape[0]
+    if weight.shape[1] != k or k % 32 != 0:
+        raise ValueError(f"linear_f32 needs weight [N, K] with K % 32 == 0, got x {tuple(x.shape)} w {tuple(weight.shape)}")
+    x2 = x.reshape(-1, k)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    x2, weight = x2.float(), weight.contiguous().float()
+    if bias is not None:
+        bias = bias.contiguous().float()
+        if bias.numel() != n:
+            raise ValueError("bias must have N elements")
+    m = x2.shape[0]
+    y = torch.empty(m, n, device=x.device, dtype=torch.float32)
+    if m:
+        status = _lib.lib().simpb_linear_f32(_ptr(y), _ptr(x2), _ptr(weight), _ptr(bias) if bias is not None else None,
+                                             m, n, k, 1 if relu else 0, _stream())
+        _lib.check(status, "simpb_linear_f32")
+    return y.reshape(x.shape[:-1] + (n,))

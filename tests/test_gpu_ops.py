@@ -123,3 +123,58 @@ def test_ops_reject_cpu_tensors():
         ops.deformable_aggregation_function(torch.zeros(1, 4, 8), torch.ones(1, 1, 2, dtype=torch.int32) * 2,
                                             torch.zeros(1, 1, dtype=torch.int32), torch.zeros(1, 1, 1, 1, 2),
                                             torch.zeros(1, 1, 1, 1, 1, 2))
+
+
+@pytest.mark.parametrize("m,n,k,relu,bias", [(89760, 256, 256, False, True), (1000, 256, 256, True, True),
+                                             (77, 96, 64, False, False), (130, 600, 512, True, True), (1, 256, 32, False, True)])
+def test_linear_f32_vs_float64(m, n, k, relu, bias):
+    """fp32 MFMA GEMM against a float64 reference: |err| <= 2e-6 * sum_k |x||w| (fp32 chain bound)."""
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.standard_normal((m, k)).astype(np.float32)).cuda()
+    w = torch.from_numpy(rs.standard_normal((n, k)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rs.standard_normal(n).astype(np.float32)).cuda() if bias else None
+    got = _ops().linear_f32(x, w, b, relu=relu)
+    want = x.double() @ w.double().t() + (b.double() if bias else 0)
+    if relu:
+        want = want.clamp(min=0)
+    bound = 2e-6 * (x.abs().double() @ w.abs().double().t()) + 1e-6
+    assert bool(((got.double() - want).abs() <= bound).all())
+
+
+def test_mlp_chain_vs_torch_modules():
+    """The fused linear_relu_ln chains against the same nn.Sequential evaluated by PyTorch (fp32,
+    the tolerance covers summation order only)."""
+    import torch.nn as nn
+    from simpb_amd.plugin import fused
+    from simpb_amd.plugin.detection2d import SparseBox2DEncoder, SparseBox2DRefinementModule
+    from simpb_amd.plugin.detection3d import SparseBox3DEncoder, SparseBox3DRefinementModule
+    torch.manual_seed(0)
+    enc = SparseBox3DEncoder(embed_dims=[128, 32, 32, 64], vel_dims=3, mode="cat", output_fc=False, in_loops=1, out_loops=4)
+    synth.load_procedural(enc, seed=3)
+    box = torch.randn(2, 77, 11)
+    want = torch.cat([enc.pos_fc(box[..., 0:3]), enc.size_fc(box[..., 3:6]), enc.yaw_fc(box[..., 6:8]), enc.vel_fc(box[..., 8:11])], -1)
+    got = enc.cuda()(box.cuda()).cpu()
+    assert got.shape == want.shape and float((got - want).abs().max()) < 2e-5
+
+    enc2 = SparseBox2DEncoder(embed_dims=256, with_sin_embed=True, in_loops=1, out_loops=2)
+    synth.load_procedural(enc2, seed=4)
+    pts = torch.rand(1, 203, 2) * 1.2 - 0.1
+    want = enc2(pts)
+    got = enc2.cuda()(pts.cuda()).cpu()
+    assert float((got - want).abs().max()) < 5e-5
+
+    ref3 = SparseBox3DRefinementModule(embed_dims=256, num_cls=10, refine_yaw=True, with_quality_estimation=True)
+    synth.load_procedural(ref3, seed=5)
+    f, e, a, dt = torch.randn(2, 45, 256), torch.randn(2, 45, 256), torch.randn(2, 45, 11), torch.tensor([0.5, 0.4])
+    w_out, w_cls, w_q = ref3(f, a, e, dt, True)
+    g_out, g_cls, g_q = ref3.cuda()(f.cuda(), a.cuda(), e.cuda(), dt.cuda(), True)
+    for g_, w_ in ((g_out, w_out), (g_cls, w_cls), (g_q, w_q)):
+        assert float((g_.cpu() - w_).abs().max()) < 5e-5
+
+    ref2 = SparseBox2DRefinementModule(embed_dims=256, num_cls=10, with_alpha_branch=True)
+    synth.load_procedural(ref2, seed=6)
+    a2 = torch.rand(2, 45, 2)
+    w_box, w_cls, _, w_al = ref2(f, a2, e)
+    g_box, g_cls, _, g_al = ref2.cuda()(f.cuda(), a2.cuda(), e.cuda())
+    for g_, w_ in ((g_box, w_box), (g_cls, w_cls), (g_al, w_al)):
+        assert float((g_.cpu() - w_).abs().max()) < 5e-5

@@ -81,3 +81,20 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def bench_linear():
+    import torch.nn.functional as F
+    for (m, n, k) in [(89760, 256, 256), (359040, 256, 256), (1536, 1024, 512), (900, 256, 256)]:
+        x = torch.randn(m, k, device="cuda")
+        w = torch.randn(n, k, device="cuda")
+        b = torch.randn(n, device="cuda")
+        t1 = time_kernel(lambda: ops.linear_f32(x, w, b), iters=20)
+        t2 = time_kernel(lambda: F.linear(x, w, b), iters=20)
+        fl = 2.0 * m * n * k
+        print(json.dumps(dict(kernel="linear_f32_mfma", m=m, n=n, k=k, us=t1 * 1e6, tflops=fl / t1 / 1e12,
+                              vendor_us=t2 * 1e6, vendor_tflops=fl / t2 / 1e12)))
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "linear":
+    bench_linear()
