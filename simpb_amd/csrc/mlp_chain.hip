@@ -72,17 +72,37 @@ __global__ __launch_bounds__(kThreads) void mlp_chain_kernel(simpb_mlp_args args
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = b;
         const float* wt = op.w + tid;  // W^T [K][D]
+        // The weights come from L2 (one coalesced row per k) and nothing else hides that latency
+        // (one workgroup per CU at these sizes), so 16 rows are requested at a time and the next
+        // 16 are already in flight while the current ones are multiplied.
+        constexpr int KU = 16;
+        float wa[KU], wb[KU];
         int k = 0;
-        for (; k + 4 <= K; k += 4) {
-          const float w0 = wt[(size_t)(k + 0) * D], w1 = wt[(size_t)(k + 1) * D];
-          const float w2 = wt[(size_t)(k + 2) * D], w3 = wt[(size_t)(k + 3) * D];
+        const int kfull = K - K % KU;
+        if (kfull > 0) {
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const float4 a = *reinterpret_cast<const float4*>(&act[cur][r][k]);
-            acc[r] = fmaf(a.x, w0, acc[r]);
-            acc[r] = fmaf(a.y, w1, acc[r]);
-            acc[r] = fmaf(a.z, w2, acc[r]);
-            acc[r] = fmaf(a.w, w3, acc[r]);
+          for (int j = 0; j < KU; ++j) wa[j] = wt[(size_t)j * D];
+        }
+        for (; k < kfull; k += KU) {
+          const bool more = k + KU < kfull;
+          if (more) {
+#pragma unroll
+            for (int j = 0; j < KU; ++j) wb[j] = wt[(size_t)(k + KU + j) * D];
+          }
+#pragma unroll
+          for (int j = 0; j < KU; j += 4) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const float4 a = *reinterpret_cast<const float4*>(&act[cur][r][k + j]);
+              acc[r] = fmaf(a.x, wa[j + 0], acc[r]);
+              acc[r] = fmaf(a.y, wa[j + 1], acc[r]);
+              acc[r] = fmaf(a.z, wa[j + 2], acc[r]);
+              acc[r] = fmaf(a.w, wa[j + 3], acc[r]);
+            }
+          }
+          if (more) {
+#pragma unroll
+            for (int j = 0; j < KU; ++j) wa[j] = wb[j];
           }
         }
         for (; k < K; ++k) {

@@ -83,12 +83,20 @@ class DeformableFeatureAggregation(BaseModule):
             cam_in = metas["projection_mat"][:, :, :3].reshape(bs, self.num_cams, -1)
             if cam_in.is_cuda:
                 from . import fused
+                from .ops import linear_f32
                 camera_embed = fused.chain_forward(self.camera_encoder, cam_in)
+                # weights_fc is linear, so weights_fc(feature[:, :, None] + camera_embed[:, None]) =
+                # weights_fc(feature)[:, :, None] + camera_embed @ W^T: one [N, 256] x [256, 416] product
+                # plus a [cams, 256] one instead of the reference's [N * cams, 256] product (:177-179)
+                logits = (linear_f32(feature, self.weights_fc.weight, self.weights_fc.bias)[:, :, None]
+                          + linear_f32(camera_embed, self.weights_fc.weight)[:, None])
             else:
                 camera_embed = self.camera_encoder(cam_in)
-            feature = feature[:, :, None] + camera_embed[:, None]
+                logits = self.weights_fc(feature[:, :, None] + camera_embed[:, None])
+        else:
+            logits = self.weights_fc(feature)
         weights = (
-            self.weights_fc(feature)
+            logits
             .reshape(bs, num_anchor, -1, self.num_groups)
             .softmax(dim=-2)
             .reshape(bs, num_anchor, self.num_cams, self.num_levels, self.num_pts, self.num_groups)
