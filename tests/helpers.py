@@ -127,12 +127,15 @@ def compare_result(res, g, prefix, box_tol=1e-3, score_tol=1e-3):
     assert p3 is not None, "3D detections differ (as a set) beyond tolerance"
     # ranking may only differ where scores are tied within tolerance
     assert np.abs(T("scores_3d").astype(np.float64) - G("scores_3d")).max() <= score_tol
-    rec2 = lambda b, s, l, c: np.concatenate([np.asarray(b, np.float64), np.asarray(s, np.float64)[:, None],
-                                              np.asarray(l, np.float64)[:, None], np.asarray(c, np.float64)[:, None]], axis=1)
-    tol2 = [box_tol * 100] * 4 + [score_tol, 0.5, 0.5]
-    p2 = _match_rows(rec2(T("boxes_2d"), T("scores_2d"), T("labels_2d"), T("camidx_2d")),
-                     rec2(G("boxes_2d"), G("scores_2d"), G("labels_2d"), G("camidx_2d")), tol2)
+    rec2 = lambda b, s, l: np.concatenate([np.asarray(b, np.float64), np.asarray(s, np.float64)[:, None],
+                                           np.asarray(l, np.float64)[:, None]], axis=1)
+    tol2 = [box_tol * 100] * 4 + [score_tol, 0.5]
+    p2 = _match_rows(rec2(T("boxes_2d"), T("scores_2d"), T("labels_2d")),
+                     rec2(G("boxes_2d"), G("scores_2d"), G("labels_2d")), tol2)
     assert p2 is not None, "2D detections differ (as a set) beyond tolerance"
+    # camidx_2d is bucketed with the reference's re-bound group list (decoder.py:216), so for sample
+    # i > 0 of a batch its length need not equal the number of 2D boxes: compared as it stands
+    assert np.array_equal(np.sort(T("camidx_2d").astype(np.int64)), np.sort(G("camidx_2d").astype(np.int64)))
     t = res["trans_matrix"]
     t = t.detach().cpu() if torch.is_tensor(t) else torch.as_tensor(t)
     assert tuple(t.shape) == tuple(G("trans_shape").tolist())
