@@ -115,6 +115,24 @@ typedef struct simpb_mlp_args {
 } simpb_mlp_args;
 int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream);
 
+/* Sampling locations of the 3D deformable aggregation in its own layout: key points of
+ * SparseBox3DKeyPointsGenerator.forward (models/detection3d/blocks.py:181-222: num_fix fixed scales x
+ * exp(wlh) plus num_learn (sigmoid(learnable) - 0.5) x exp(wlh), rotated by yaw, + centre) projected by
+ * DeformableFeatureAggregation.project_points (models/blocks.py:198-213: / clamp(depth, 1e-5), / image_wh).
+ *   anchor f32 [bs, A, 11]; learnable f32 [bs, A, num_learn, 3] (output of learnable_fc);
+ *   fix_scale f32 [num_fix, 3]; projection_mat f32 [bs, cams, 4, 4]; image_wh f32 [bs, cams, 2]
+ *   loc f32 [bs, A, num_fix + num_learn, cams, 2]; key_points f32 [bs, A, P, 3] or NULL */
+int simpb_dfa_points(float* loc, float* key_points, const float* anchor, const float* learnable,
+                     const float* fix_scale, const float* projection_mat, const float* image_wh, int batch_size,
+                     int num_anchors, int num_fix, int num_learn, int num_cams, void* stream);
+
+/* Weights of the 3D deformable aggregation in its own layout (models/blocks.py:164-187 + :132-143):
+ *   feat_logits f32 [bs, A, lvl*pts*groups] = weights_fc(feature + anchor_embed)
+ *   cam_logits  f32 [bs, cams, lvl*pts*groups] = camera_embed @ weights_fc.weight^T (no bias)
+ *   weights     f32 [bs, A, pts, cams, lvl, groups] = softmax over (cam, lvl, pts) per group of their sum */
+int simpb_dfa_weights(float* weights, const float* feat_logits, const float* cam_logits, int batch_size,
+                      int num_anchors, int num_cams, int num_levels, int num_pts, int num_groups, void* stream);
+
 /* Adaptive query allocation, replaces DynamicQueryAllocation.projection_allocation
  * (models/allocation.py:27-144) in three steps; the caller reads `count` back between steps 2
  * and 3 to size the 2D query set (the reference does the same with .tolist() at :94).

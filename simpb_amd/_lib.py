@@ -21,6 +21,8 @@ SIGNATURES = {
     "simpb_ms_deform_attn_grouped_forward": ([_P] * 7 + [_I] * 8 + [_P], _I),
     "simpb_linear_f32": ([_P] * 4 + [_I] * 4 + [_P], _I),
     "simpb_mlp_chain_forward": ([_P, _P], _I),
+    "simpb_dfa_points": ([_P] * 7 + [_I] * 5 + [_P], _I),
+    "simpb_dfa_weights": ([_P] * 3 + [_I] * 6 + [_P], _I),
     "simpb_alloc_project": ([_P] * 5 + [_I] * 3 + [_F] * 5 + [_P], _I),
     "simpb_alloc_compact": ([_P] * 3 + [_I] * 3 + [_P], _I),
     "simpb_alloc_group_start": ([_P] * 3 + [_I] * 3 + [_P], _I),

@@ -57,6 +57,9 @@ class DeformableFeatureAggregation(BaseModule):
         nn.init.constant_(self.output_proj.bias, 0.0)
 
     def forward(self, instance_feature, anchor, anchor_embed, feature_maps, metas, **kwargs):
+        if (instance_feature.is_cuda and self.camera_encoder is not None and metas.get("image_wh") is not None
+                and getattr(self.kps_generator, "num_learnable_pts", 0) > 0):
+            return self._forward_fused(instance_feature, anchor, anchor_embed, feature_maps, metas)
         bs, num_anchor = instance_feature.shape[:2]
         key_points = self.kps_generator(anchor, instance_feature)
         weights = self._get_weights(instance_feature, anchor_embed, metas)
@@ -68,6 +71,41 @@ class DeformableFeatureAggregation(BaseModule):
         weights = weights.permute(0, 1, 4, 2, 3, 5).contiguous().reshape(
             bs, num_anchor, self.num_pts, self.num_cams, self.num_levels, self.num_groups)
         features = DAF(*feature_maps, points_2d, weights).reshape(bs, num_anchor, self.embed_dims)
+        output = self.proj_drop(self.output_proj(features))
+        if self.residual_mode == "add":
+            output = output + instance_feature
+        elif self.residual_mode == "cat":
+            output = torch.cat([output, instance_feature], dim=-1)
+        return output
+
+    def _forward_fused(self, instance_feature, anchor, anchor_embed, feature_maps, metas):
+        """Same dataflow as forward(), with the operand producers as two HIP kernels writing the
+        aggregation kernel's own layouts (csrc/dfa_prep.hip) instead of ~25 PyTorch kernels."""
+        from .. import _lib
+        from . import fused
+        from .ops import _ptr, _stream, linear_f32
+        lib = _lib.lib()
+        bs, num_anchor = instance_feature.shape[:2]
+        kps = self.kps_generator
+        dev = instance_feature.device
+        anchor_c = anchor.contiguous().float()
+        proj = metas["projection_mat"].contiguous().float()
+        wh = metas["image_wh"].contiguous().float()
+        learn = kps.learnable_fc(instance_feature).contiguous()
+        num_fix = kps.fix_scale.shape[0]
+        loc = torch.empty(bs, num_anchor, self.num_pts, self.num_cams, 2, device=dev)
+        _lib.check(lib.simpb_dfa_points(_ptr(loc), None, _ptr(anchor_c), _ptr(learn), _ptr(kps.fix_scale), _ptr(proj),
+                                        _ptr(wh), bs, num_anchor, num_fix, kps.num_learnable_pts, self.num_cams,
+                                        _stream()), "simpb_dfa_points")
+        feature = instance_feature + anchor_embed
+        cam_embed = fused.chain_forward(self.camera_encoder, proj[:, :, :3].reshape(bs, self.num_cams, -1))
+        feat_logits = linear_f32(feature, self.weights_fc.weight, self.weights_fc.bias)
+        cam_logits = linear_f32(cam_embed, self.weights_fc.weight)
+        weights = torch.empty(bs, num_anchor, self.num_pts, self.num_cams, self.num_levels, self.num_groups, device=dev)
+        _lib.check(lib.simpb_dfa_weights(_ptr(weights), _ptr(feat_logits), _ptr(cam_logits), bs, num_anchor,
+                                         self.num_cams, self.num_levels, self.num_pts, self.num_groups, _stream()),
+                   "simpb_dfa_weights")
+        features = DAF(*feature_maps, loc, weights).reshape(bs, num_anchor, self.embed_dims)
         output = self.proj_drop(self.output_proj(features))
         if self.residual_mode == "add":
             output = output + instance_feature

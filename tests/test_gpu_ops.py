@@ -178,3 +178,35 @@ def test_mlp_chain_vs_torch_modules():
     g_box, g_cls, _, g_al = ref2.cuda()(f.cuda(), a2.cuda(), e.cuda())
     for g_, w_ in ((g_box, w_box), (g_cls, w_cls), (g_al, w_al)):
         assert float((g_.cpu() - w_).abs().max()) < 5e-5
+
+
+def test_dfa_producers_vs_oracle():
+    """dfa_points / dfa_weights against the oracle's key_points -> project_points and dfa_weights
+    (same parameters), in the aggregation kernel's layouts."""
+    R = _oracle()
+    from simpb_amd import configs, plugin
+    cfg = configs.simpb_plus(anchor=synth.anchors(900))["model"]["head"]["deformable_model"]
+    dfa = plugin.build_from_cfg(cfg, plugin.ATTENTION).eval()
+    synth.load_procedural(dfa, seed=2)
+    p = {"m." + k: v for k, v in dfa.state_dict().items()}
+    bs, A = 2, 61
+    feat = torch.from_numpy(synth.randn("dfa.feat", (bs, A, 256)))
+    emb = torch.from_numpy(synth.randn("dfa.emb", (bs, A, 256)))
+    anchor = torch.from_numpy(synth.anchors(A, seed=4))[None].repeat(bs, 1, 1)
+    metas = synth.frame_metas(bs, 0)
+    kp = R.key_points(p, "m.kps_generator", anchor, feat)
+    want_loc = R.project_points(kp, metas["projection_mat"], metas["image_wh"]).permute(0, 2, 3, 1, 4)
+    want_w = R.dfa_weights(p, "m", feat, emb, metas["projection_mat"]).permute(0, 1, 4, 2, 3, 5)
+    got = {}
+    from simpb_amd.plugin import blocks
+    orig = blocks.DAF
+    blocks.DAF = lambda f, ss, ssi, loc, w: got.update(loc=loc, w=w) or torch.zeros(bs, A, 256, device="cuda")
+    try:
+        dfa.cuda()
+        m = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in metas.items()}
+        with torch.no_grad():
+            dfa(feat.cuda(), anchor.cuda(), emb.cuda(), [None, None, None], m)
+    finally:
+        blocks.DAF = orig
+    assert float((got["loc"].cpu() - want_loc).abs().max()) <= 1e-4 * max(1.0, float(want_loc.abs().max()) * 1e-2)
+    assert float((got["w"].cpu() - want_w).abs().max()) <= 1e-6
