@@ -24,6 +24,7 @@ constexpr int kMaxDim = 256;
 template <int R>
 __global__ __launch_bounds__(kThreads) void mlp_chain_kernel(simpb_mlp_args args) {
   __shared__ float act[2][R][kMaxDim];
+  __shared__ float part[4][R][kMaxDim];  // per-wave partial sums of the split-K linear
   const simpb_mlp_chain& ch = args.chain[blockIdx.y];
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * R;
@@ -66,46 +67,86 @@ __global__ __launch_bounds__(kThreads) void mlp_chain_kernel(simpb_mlp_args args
     const simpb_mlp_op& op = ch.ops[o];
     if (op.type == SIMPB_MLP_LINEAR) {
       const int K = op.in_dim, D = op.out_dim;
+      if ((D & 3) == 0 && K >= 16) {
+        // Wide form. What bounds a layer is streaming W^T (up to 256 KiB) from L2 into ONE workgroup,
+        // so the reduction is split over the 4 waves and each lane takes 4 adjacent columns: every
+        // load is 16 B per lane (a 1-KiB row of W^T per wave-instruction), 4x the bytes in flight of a
+        // scalar-column layout. Partial sums meet in LDS.
+        const int lane = tid & 63, wave = tid >> 6;
+        const int c4 = lane * 4;
+        const int kq = (K + 3) / 4;               // k-range per wave, in rows
+        const int kb = wave * kq, ke = min(K, kb + kq);
+        float4 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < D) {
+          const float* wt = op.w + c4;
+          constexpr int KU = 8;
+          float4 wa[KU], wb[KU];
+          int k = kb;
+          const int kfull = kb + ((ke - kb) / KU) * KU;
+          if (kfull > kb) {
+#pragma unroll
+            for (int j = 0; j < KU; ++j) wa[j] = *reinterpret_cast<const float4*>(wt + (size_t)(k + j) * D);
+          }
+          for (; k < kfull; k += KU) {
+            const bool more = k + KU < kfull;
+            if (more) {
+#pragma unroll
+              for (int j = 0; j < KU; ++j) wb[j] = *reinterpret_cast<const float4*>(wt + (size_t)(k + KU + j) * D);
+            }
+#pragma unroll
+            for (int j = 0; j < KU; ++j) {
+#pragma unroll
+              for (int r = 0; r < R; ++r) {
+                const float a = act[cur][r][k + j];
+                acc[r].x = fmaf(a, wa[j].x, acc[r].x);
+                acc[r].y = fmaf(a, wa[j].y, acc[r].y);
+                acc[r].z = fmaf(a, wa[j].z, acc[r].z);
+                acc[r].w = fmaf(a, wa[j].w, acc[r].w);
+              }
+            }
+            if (more) {
+#pragma unroll
+              for (int j = 0; j < KU; ++j) wa[j] = wb[j];
+            }
+          }
+          for (; k < ke; ++k) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wt + (size_t)k * D);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const float a = act[cur][r][k];
+              acc[r].x = fmaf(a, w4.x, acc[r].x);
+              acc[r].y = fmaf(a, w4.y, acc[r].y);
+              acc[r].z = fmaf(a, w4.z, acc[r].z);
+              acc[r].w = fmaf(a, w4.w, acc[r].w);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(&part[wave][r][c4]) = acc[r];
+        }
+        __syncthreads();
+        // thread t = column t: sum the 4 partials (fixed order), bias, activation
+        if (tid < D) {
+          const float b = op.b ? op.b[tid] : 0.f;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float v = ((part[0][r][tid] + part[1][r][tid]) + (part[2][r][tid] + part[3][r][tid])) + b;
+            act[cur ^ 1][r][tid] = op.relu ? fmaxf(v, 0.f) : v;
+          }
+        }
+        __syncthreads();
+        cur ^= 1;
+        width = D;
+        continue;
+      }
       if (tid < D) {
         float acc[R];
         const float b = op.b ? op.b[tid] : 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = b;
         const float* wt = op.w + tid;  // W^T [K][D]
-        // The weights come from L2 (one coalesced row per k) and nothing else hides that latency
-        // (one workgroup per CU at these sizes), so 16 rows are requested at a time and the next
-        // 16 are already in flight while the current ones are multiplied.
-        constexpr int KU = 16;
-        float wa[KU], wb[KU];
-        int k = 0;
-        const int kfull = K - K % KU;
-        if (kfull > 0) {
-#pragma unroll
-          for (int j = 0; j < KU; ++j) wa[j] = wt[(size_t)j * D];
-        }
-        for (; k < kfull; k += KU) {
-          const bool more = k + KU < kfull;
-          if (more) {
-#pragma unroll
-            for (int j = 0; j < KU; ++j) wb[j] = wt[(size_t)(k + KU + j) * D];
-          }
-#pragma unroll
-          for (int j = 0; j < KU; j += 4) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              const float4 a = *reinterpret_cast<const float4*>(&act[cur][r][k + j]);
-              acc[r] = fmaf(a.x, wa[j + 0], acc[r]);
-              acc[r] = fmaf(a.y, wa[j + 1], acc[r]);
-              acc[r] = fmaf(a.z, wa[j + 2], acc[r]);
-              acc[r] = fmaf(a.w, wa[j + 3], acc[r]);
-            }
-          }
-          if (more) {
-#pragma unroll
-            for (int j = 0; j < KU; ++j) wa[j] = wb[j];
-          }
-        }
-        for (; k < K; ++k) {
+        for (int k = 0; k < K; ++k) {
           const float w0 = wt[(size_t)k * D];
 #pragma unroll
           for (int r = 0; r < R; ++r) acc[r] = fmaf(act[cur][r][k], w0, acc[r]);
