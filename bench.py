@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--capacity", type=int, default=1536, help="static 2D query slots (N2 is ~1.1-1.2k at R50 704x256)")
     ap.add_argument("--eager", action="store_true", help="do not replay the frame as a hipGraph")
     ap.add_argument("--meter-frames", type=int, default=8, help="instrumented eager frames for the roofline leg")
-    ap.add_argument("--conv-search", action="store_true", help="let MIOpen benchmark conv algorithms (cudnn.benchmark)")
+    ap.add_argument("--no-conv-search", action="store_true",
+                    help="do not let MIOpen benchmark convolution algorithms during warm-up (cudnn.benchmark off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
@@ -192,7 +193,7 @@ def main():
 
     from simpb_amd.dist import gather_detections, pack_detections
     from simpb_amd.runner import FrameRunner
-    torch.backends.cudnn.benchmark = bool(args.conv_search)
+    torch.backends.cudnn.benchmark = not args.no_conv_search
     model = build_model(args, device)
     total = args.warmup + args.steps + args.meter_frames
     imgs = make_frames(args, device, total)

@@ -18,13 +18,13 @@ extern "C" int simpb_check_launch(void);
 
 namespace {
 
-constexpr int kThreads = 256;
 constexpr int kMaxDim = 256;
 
-template <int R>
-__global__ __launch_bounds__(kThreads) void mlp_chain_kernel(simpb_mlp_args args) {
+template <int R, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mlp_chain_kernel(simpb_mlp_args args) {
+  constexpr int kThreads = WAVES * 64;
   __shared__ float act[2][R][kMaxDim];
-  __shared__ float part[4][R][kMaxDim];  // per-wave partial sums of the split-K linear
+  __shared__ float part[WAVES][R][kMaxDim];  // per-wave partial sums of the split-K linear
   const simpb_mlp_chain& ch = args.chain[blockIdx.y];
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * R;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void mlp_chain_kernel(simpb_mlp_args args
         // scalar-column layout. Partial sums meet in LDS.
         const int lane = tid & 63, wave = tid >> 6;
         const int c4 = lane * 4;
-        const int kq = (K + 3) / 4;               // k-range per wave, in rows
+        const int kq = (K + WAVES - 1) / WAVES;    // k-range per wave, in rows
         const int kb = wave * kq, ke = min(K, kb + kq);
         float4 acc[R];
 #pragma unroll
@@ -131,7 +131,10 @@ __global__ __launch_bounds__(kThreads) void mlp_chain_kernel(simpb_mlp_args args
           const float b = op.b ? op.b[tid] : 0.f;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const float v = ((part[0][r][tid] + part[1][r][tid]) + (part[2][r][tid] + part[3][r][tid])) + b;
+            float v = part[0][r][tid];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) v += part[w][r][tid];  // fixed order: deterministic
+            v += b;
             act[cur ^ 1][r][tid] = op.relu ? fmaxf(v, 0.f) : v;
           }
         }
@@ -228,8 +231,10 @@ extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream)
     }
   }
   (void)hipGetLastError();
-  constexpr int R = 8;
+  // 4 rows x 8 waves: enough workgroups to occupy every CU at ~900-1500 rows, and 8 waves per CU
+  // keep 64 KiB of weight rows in flight
+  constexpr int R = 4, WAVES = 8;
   dim3 grid((args->num_rows + R - 1) / R, args->num_chains);
-  hipLaunchKernelGGL(mlp_chain_kernel<R>, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream), *args);
+  hipLaunchKernelGGL((mlp_chain_kernel<R, WAVES>), grid, dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream), *args);
   return simpb_check_launch();
 }
