@@ -77,6 +77,17 @@ int simpb_ms_deform_attn_grouped_forward(
 int simpb_linear_f32(float* y, const float* x, const float* weight, const float* bias, int M, int N, int K,
                      int relu, void* stream);
 
+/* Attention core of torch.nn.MultiheadAttention (between in_proj and out_proj), exact fp32, flash
+ * style, head_dim = 64: out[b,q,h*64+d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d].
+ * q/k/v/out are [batch, N, heads*64] with row strides ldq/ldk/ldv/ldo (floats; batches are N*ld apart),
+ * so slices of a fused projection buffer can be passed as they are. q and k 16-byte aligned.
+ * Camera-grouped form (both tables non-NULL, num_key == num_query): slot q only attends slots of its
+ * own group: query_cam i32 [N] (-1 = slot outside every group -> zeros), group_start i32 [cams+1];
+ * this equals the reference's additive -inf block mask + nan_to_num (models/group_attn.py:104-131). */
+int simpb_attention_f32(float* out, const float* q, const float* k, const float* v, const int* query_cam,
+                        const int* group_start, int batch_size, int num_heads, int head_dim, int num_query,
+                        int num_key, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+
 /* Fused small-MLP chains: a whole `linear_relu_ln` stack (models/blocks.py:32-43) -- [Linear, ReLU]*,
  * LayerNorm, ..., optional last Linear and Scale -- in one launch; up to 4 independent chains over
  * the same rows share it (e.g. the pos/size/yaw/vel branches of SparseBox3DEncoder,

@@ -199,7 +199,6 @@ class SimPBHead(BaseModule):
                 anchor2d, ref_depth2d, ref_trans_mask, ref_trans_shape, _, _, ref_query_groups, _ = layer(
                     anchor, metas, dense=False, capacity=cap)
                 alloc = layer.last
-                group_cam = alloc.query_cam if ref_query_groups is None else None
                 instance_feature = gather_rows(instance_feature, alloc.q2a)  # :438
                 anchor_embed2d = self.anchor_encoder2d(anchor2d)
                 ref_pts2d_list.append(anchor2d[..., :2])
@@ -214,7 +213,7 @@ class SimPBHead(BaseModule):
             elif op == "qg_self_attn":
                 instance_feature = self.graph_model2d(i, query=instance_feature, value=instance_feature,
                                                       query_pos=anchor_embed2d, query_groups=ref_query_groups,
-                                                      query_cam=group_cam)
+                                                      query_cam=alloc.query_cam, group_start=alloc.group_start)
             elif op == "qg_cross_attn":
                 instance_feature = layer(query=instance_feature, query_pos=anchor_embed2d,
                                          reference_points=anchor2d.unsqueeze(2), query_groups=ref_query_groups,

@@ -75,15 +75,16 @@ def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
     return layers
 
 
-def mha_forward(attn, query, key, value, groups=None, same_qk=False, query_cam=None):
+def mha_forward(attn, query, key, value, groups=None, same_qk=False, query_cam=None, group_start=None):
     """Arithmetic of torch.nn.MultiheadAttention.forward for batch-first [bs, N, E] inputs, using
     `attn` (an nn.MultiheadAttention) purely as the parameter container so checkpoint keys stay
     `attn.in_proj_weight/in_proj_bias/out_proj.*`.
 
-    groups: list of (start, end) query/key blocks. The reference builds an N x N additive mask
-    that is 0 inside a block and -inf across (group_attn.py:104-113); softmax under that mask is
-    exactly an independent softmax per block, which is what is computed here (no mask tensor,
-    ~1/len(groups) of the score work)."""
+    Camera groups: the reference builds an N x N additive mask that is 0 inside a block and -inf
+    across (group_attn.py:104-113); softmax under that mask is exactly an independent softmax per
+    block. On the GPU the attention core is csrc/attention.hip, which takes the group structure as
+    device tables (query_cam, group_start) -- no mask tensor, no cross-group score work, static
+    shapes. `groups` (a Python list of (start, end)) is the CPU/legacy form of the same thing."""
     e = attn.embed_dim
     h = attn.num_heads
     hd = e // h
@@ -96,17 +97,16 @@ def mha_forward(attn, query, key, value, groups=None, same_qk=False, query_cam=N
         q = F.linear(query, w[:e], b[:e])
         k = F.linear(key, w[e: 2 * e], b[e: 2 * e])
     v = F.linear(value, w[2 * e:], b[2 * e:])
+    if q.is_cuda and hd == 64:
+        from .ops import attention_f32
+        if query_cam is not None and group_start is None:
+            raise ValueError("grouped attention on the GPU needs the device group table (group_start)")
+        o = attention_f32(q, k, v, h, query_cam, group_start)
+        return F.linear(o, attn.out_proj.weight, attn.out_proj.bias)
     q = q.reshape(bs, nq, h, hd).transpose(1, 2)
     k = k.reshape(bs, -1, h, hd).transpose(1, 2)
     v = v.reshape(bs, -1, h, hd).transpose(1, 2)
-    if query_cam is not None:
-        # static-shape form of the same block structure: the camera id of every slot lives on the
-        # device (-1 = capacity slot outside every group), so the mask is built there and no shape
-        # depends on the per-frame counts. Rows with no admissible key come out NaN -> 0 (:131).
-        same = (query_cam[:, None] == query_cam[None, :]) & (query_cam[:, None] >= 0)
-        mask = torch.zeros(same.shape, dtype=q.dtype, device=q.device).masked_fill_(~same, float("-inf"))
-        o = torch.nan_to_num(F.scaled_dot_product_attention(q, k, v, attn_mask=mask))
-    elif groups is None or len(groups) <= 1:
+    if groups is None or len(groups) <= 1:
         o = F.scaled_dot_product_attention(q, k, v)
     else:
         o = torch.zeros_like(q)  # rows outside every block are fully masked -> nan_to_num -> 0 (:131)

@@ -203,3 +203,40 @@ def linear_f32(x, weight, bias=None, relu=False):
                                              m, n, k, 1 if relu else 0, _stream())
         _lib.check(status, "simpb_linear_f32")
     return y.reshape(x.shape[:-1] + (n,))
+
+
+def attention_f32(q, k, v, num_heads, query_cam=None, group_start=None):
+    """softmax(q k^T / sqrt(hd)) v per head, fp32, flash style (csrc/attention.hip). q [bs, Nq, E],
+    k/v [bs, Nk, E] with unit inner stride (row-strided views of a fused projection are fine), E =
+    num_heads * 64. With query_cam/group_start: camera-grouped self-attention over one slot set."""
+    _require_gpu(q, k, v)
+    bs, nq, e = q.shape
+    nk = k.shape[1]
+    hd = e // num_heads
+    if hd != 64 or e != num_heads * 64 or k.shape[2] != e or v.shape[2] != e or v.shape[1] != nk:
+        raise ValueError("attention_f32 needs head_dim 64 and matching q/k/v widths")
+
+    def rows(t, n):
+        if t.dtype != torch.float32:
+            t = t.float()
+        if t.stride(2) != 1 or (bs > 1 and t.stride(0) != n * t.stride(1)) or t.stride(1) % 4 or t.data_ptr() % 16:
+            t = t.contiguous()
+        return t, t.stride(1)
+
+    q, ldq = rows(q, nq)
+    k, ldk = rows(k, nk)
+    v, ldv = rows(v, nk)
+    out = torch.empty(bs, nq, e, device=q.device, dtype=torch.float32)
+    if (query_cam is None) != (group_start is None):
+        raise ValueError("query_cam and group_start go together")
+    if query_cam is not None:
+        if nk != nq or query_cam.dtype != torch.int32 or group_start.dtype != torch.int32 or query_cam.numel() != nq:
+            raise ValueError("grouped attention needs i32 query_cam [N] / group_start [cams+1] over one slot set")
+    if nq == 0:
+        return out
+    status = _lib.lib().simpb_attention_f32(
+        _ptr(out), _ptr(q), _ptr(k), _ptr(v), _ptr(query_cam) if query_cam is not None else None,
+        _ptr(group_start) if group_start is not None else None, bs, num_heads, hd, nq, nk, ldq, ldk, ldv, e,
+        1.0 / (hd ** 0.5), _stream())
+    _lib.check(status, "simpb_attention_f32")
+    return out

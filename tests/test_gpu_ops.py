@@ -210,3 +210,40 @@ def test_dfa_producers_vs_oracle():
         blocks.DAF = orig
     assert float((got["loc"].cpu() - want_loc).abs().max()) <= 1e-4 * max(1.0, float(want_loc.abs().max()) * 1e-2)
     assert float((got["w"].cpu() - want_w).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("bs,nq,nk", [(1, 900, 600), (2, 77, 77), (1, 33, 1)])
+def test_attention_f32_vs_float64(bs, nq, nk):
+    rs = np.random.RandomState(8)
+    q = torch.from_numpy(rs.standard_normal((bs, nq, 512)).astype(np.float32))
+    k = torch.from_numpy(rs.standard_normal((bs, nk, 512)).astype(np.float32))
+    v = torch.from_numpy(rs.standard_normal((bs, nk, 512)).astype(np.float32))
+    got = _ops().attention_f32(q.cuda(), k.cuda(), v.cuda(), 8).cpu()
+    qd, kd, vd = (t.double().reshape(bs, -1, 8, 64).transpose(1, 2) for t in (q, k, v))
+    want = (torch.softmax(qd @ kd.transpose(-1, -2) / 8.0, -1) @ vd).transpose(1, 2).reshape(bs, nq, 512)
+    assert float((got.double() - want).abs().max()) < 2e-5
+
+
+def test_attention_f32_grouped_with_pads_and_strided_views():
+    """Camera-grouped form against the reference's formulation (dense scores + additive -inf block
+    mask + nan_to_num, group_attn.py:104-131), with capacity pads (query_cam = -1), an empty group,
+    and q/k passed as strided halves of one fused projection buffer."""
+    rs = np.random.RandomState(9)
+    bs, n = 2, 150
+    bounds = [0, 40, 40, 77, 100, 131, 140]  # group 1 empty; slots 140..149 are capacity pads
+    cam = torch.full((n,), -1, dtype=torch.int32)
+    for c in range(6):
+        cam[bounds[c]:bounds[c + 1]] = c
+    qk = torch.from_numpy(rs.standard_normal((bs, n, 1024)).astype(np.float32))
+    v = torch.from_numpy(rs.standard_normal((bs, n, 512)).astype(np.float32))
+    qk_d = qk.cuda()
+    got = _ops().attention_f32(qk_d[..., :512], qk_d[..., 512:], v.cuda(), 8, cam.cuda(),
+                               torch.tensor(bounds, dtype=torch.int32).cuda()).cpu()
+    mask = torch.full((n, n), float("-inf"), dtype=torch.float64)
+    for c in range(6):
+        mask[bounds[c]:bounds[c + 1], bounds[c]:bounds[c + 1]] = 0
+    qd, kd, vd = (t.double().reshape(bs, n, 8, 64).transpose(1, 2) for t in (qk[..., :512], qk[..., 512:], v))
+    want = torch.nan_to_num(torch.softmax(qd @ kd.transpose(-1, -2) / 8.0 + mask, -1)) @ vd
+    want = want.transpose(1, 2).reshape(bs, n, 512)
+    assert float((got.double() - want).abs().max()) < 2e-5
+    assert float(got[:, 140:].abs().max()) == 0.0
