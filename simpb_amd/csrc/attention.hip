@@ -55,8 +55,11 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
       lo = min(lo, __shfl_xor(lo, m));
       hi = max(hi, __shfl_xor(hi, m));
     }
-    kb = lo;
-    ke = min(hi, Nk);
+    // a tile made only of capacity slots (cam -1) has no group at all: empty key range. (lo stays
+    // INT_MAX there; adding the wave offset to it would wrap around.)
+    const bool any = hi > lo;
+    kb = any ? lo : 0;
+    ke = any ? min(hi, Nk) : 0;
   }
 
   // Q^T operand: lane (query qi, half) holds Q[query][32*half + s], s = 0..31, pre-scaled
