@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--meter-frames", type=int, default=8, help="instrumented eager frames for the roofline leg")
     ap.add_argument("--no-conv-search", action="store_true",
                     help="do not let MIOpen benchmark convolution algorithms during warm-up (cudnn.benchmark off)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
@@ -184,7 +185,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    if os.environ.get("SIMPB_BENCH_DEVICE") is not None:  # rehearsal of N > 1 on a one-GPU box
+        local_rank = int(os.environ["SIMPB_BENCH_DEVICE"])
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     # host-side torch ops in the frame loop are tiny; keep the intra-op pool from oversubscribing
@@ -207,10 +213,13 @@ def main():
         nonlocal gathered
         results = runner.step(imgs[f % len(imgs)], metas[f], force_eager=force_eager)
         if dist is not None:  # detections of every stream to every rank, off the compute stream
-            rec = pack_detections(results, device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                gathered = gather_detections(rec, gathered)
+            if args.backend == "nccl":
+                rec = pack_detections(results, device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    gathered = gather_detections(rec, gathered)
+            else:
+                gathered = gather_detections(pack_detections(results), gathered)
         return results
 
     for f in range(args.warmup):
@@ -240,7 +249,7 @@ def main():
             torch.cuda.synchronize()
             ksum = kt.summary()
 
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
