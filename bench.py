@@ -245,7 +245,7 @@ def main():
         with KernelMeter(args.meter_frames) as kt:
             kt.start()
             for f in range(args.warmup + args.steps, total):
-                step(f, force_eager=True)
+                runner.step(imgs[f % len(imgs)], metas[f], force_eager=True)  # rank-local: no collective here
             torch.cuda.synchronize()
             ksum = kt.summary()
 
