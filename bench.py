@@ -74,7 +74,7 @@ class KernelMeter:
         def msda(value, ss, lsi, loc, aw, qcam):
             out = self.msda_orig(value, ss, lsi, loc, aw, qcam)
             if self.enabled:
-                self.msda_calls.append((tuple(loc.shape), value.shape[-1]))
+                self.msda_calls.append((tuple(loc.shape), value.shape[-1], qcam))
             return out
 
         self.blocks.DAF = daf
@@ -114,8 +114,10 @@ class KernelMeter:
         d = self._durations(self.MSDA)
         if d and len(d) == len(self.msda_calls):
             nbytes = 0.0
-            for (bs, nq, heads, lvls, pts, _), ch in self.msda_calls:
-                # per query: heads*lvls*pts samples * 4 taps * ch * 4 B + loc + attn + out
+            for (bs, nq, heads, lvls, pts, _), ch, qcam in self.msda_calls:
+                # per query: heads*lvls*pts samples * 4 taps * ch * 4 B + loc + attn + out; capacity slots
+                # outside every camera group (query_cam < 0) are skipped by the kernel and not counted
+                nq = int((qcam >= 0).sum())
                 nbytes += bs * nq * (heads * lvls * pts * 4 * ch * 4 + heads * lvls * pts * 3 * 4 + heads * ch * 4)
             n = len(d)
             out["msda"] = dict(kernel="msda_grouped_fwd", secs=sum(d) / n, nbytes=nbytes / n, launches=n)
