@@ -122,3 +122,142 @@ class FrameRunner:
         self.head.instance_bank.metas = self.prev_metas
         results = SparseBox3DDecoder.decode_static_host(rec3d.numpy(), rec2d.numpy(), self.head.num_cams)
         return [{"img_bbox": r} for r in results]
+
+
+class PipelinedRunner(FrameRunner):
+    """FrameRunner with the backbone of frame t+1 overlapped with the decoder of frame t.
+
+    The decoder of frame t needs the bank the decoder of frame t-1 wrote, so decoders cannot overlap
+    each other; but backbone+FPN of the next frame depends on nothing but its images. Many decoder
+    kernels are small and leave most of the 256 CUs idle, while the convolutions fill the chip, so the
+    two run side by side on separate HIP streams: step(t) launches backbone(t) and decoder(t-1) together
+    and returns the detections of frame t-1 (one frame of latency for throughput; flush() returns the
+    last frame). Two feature buffers alternate; each (backbone, decoder) x (buffer) pair is its own
+    hipGraph once warm, so the steady state is two graph launches per step."""
+
+    def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True):
+        super().__init__(model, batch_size, image_hw, capacity, device, use_graph)
+        dev = self.device
+        self.s_bb = torch.cuda.Stream(device=dev)
+        self.s_head = torch.cuda.Stream(device=dev)
+        self.imgs = [self.img, torch.zeros_like(self.img)]
+        self.fm = [None, None]              # feature maps of the frame last produced into each slot
+        self.bb_graph = [None, None]
+        self.bb_out = [None, None]
+        self.bb_runs = [0, 0]
+        self.head_graph = [None, None]
+        self.head_out = [None, None]
+        self.head_runs = [0, 0]
+        self.pending = None                 # (frame index, metas) whose features exist but decoder has not run
+        self.count = 0
+
+    def _run_backbone(self, slot, force_eager):
+        """Enqueue backbone+FPN of the image in slot `slot` on s_bb."""
+        with torch.cuda.stream(self.s_bb):
+            if self.use_graph and not force_eager and self.bb_graph[slot] is None and self.bb_runs[slot] >= 1:
+                self.s_bb.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.s_bb):
+                    self.bb_out[slot] = self.model.extract_feat(self.imgs[slot])
+                self.bb_graph[slot] = g
+                self.head_graph[slot] = None  # a decoder graph bound to the old buffer is stale
+                self.head_runs[slot] = 0
+            if self.bb_graph[slot] is not None and not force_eager:
+                self.bb_graph[slot].replay()
+                self.fm[slot] = self.bb_out[slot]
+            else:
+                self.fm[slot] = self.model.extract_feat(self.imgs[slot])
+            self.bb_runs[slot] += 1
+
+    def _decode(self, fm, dmetas, aug):
+        outs = self.head(fm, dmetas)
+        alloc = outs["alloc_list"][-1]
+        rec3d, rec2d = self.head.decoder.decode_static_device(
+            outs["classification"], outs["prediction"], outs["instance_id"], outs["quality"],
+            outs["classification2d"], outs["prediction2d"], alloc, aug)
+        return rec3d, rec2d, torch.stack([a.overflow[0] for a in outs["alloc_list"]])
+
+    def _run_head(self, slot, dmetas, aug, warm, force_eager):
+        """Enqueue the decoder of the frame whose features sit in slot `slot` on s_head."""
+        with torch.cuda.stream(self.s_head):
+            graph_ok = (self.use_graph and not force_eager and warm and self.bb_graph[slot] is not None
+                        and self.fm[slot] is self.bb_out[slot])
+            if graph_ok and self.head_graph[slot] is None and self.head_runs[slot] >= 1:
+                self.s_head.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.s_head):
+                    self.head_out[slot] = self._decode(self.fm[slot], dmetas, aug)
+                self.head_graph[slot] = g
+            if graph_ok and self.head_graph[slot] is not None:
+                self.head_graph[slot].replay()
+                rec = self.head_out[slot]
+                self.stats["replay"] += 1
+            else:
+                rec = self._decode(self.fm[slot], dmetas, aug)
+                self.stats["eager"] += 1
+                if graph_ok:
+                    self.head_runs[slot] += 1
+            return rec
+
+    def _finish(self, rec, metas):
+        with torch.cuda.stream(self.s_head):
+            if self.host3d is None:
+                self.host3d = torch.empty(rec[0].shape, dtype=rec[0].dtype).pin_memory()
+                self.host2d = torch.empty(rec[1].shape, dtype=rec[1].dtype).pin_memory()
+                self.host_flag = torch.empty(rec[2].shape, dtype=rec[2].dtype).pin_memory()
+            self.host3d.copy_(rec[0], non_blocking=True)
+            self.host2d.copy_(rec[1], non_blocking=True)
+            self.host_flag.copy_(rec[2], non_blocking=True)
+        self.s_head.synchronize()
+        if bool(self.host_flag.any()):
+            raise RuntimeError(f"2D query set exceeded the static capacity {self.capacity}; use a larger capacity")
+        self.prev_metas = dict(img_metas=metas["img_metas"])
+        results = SparseBox3DDecoder.decode_static_host(self.host3d.numpy(), self.host2d.numpy(), self.head.num_cams)
+        return [{"img_bbox": r} for r in results]
+
+    def _stage_head_inputs(self, metas):
+        """Per-frame decoder inputs (projection matrices, ego-motion, time step) of the PENDING frame."""
+        with torch.cuda.stream(self.s_head):
+            self.pin_proj.copy_(metas["projection_mat"] if not metas["projection_mat"].is_cuda else metas["projection_mat"].cpu())
+            self.proj.copy_(self.pin_proj, non_blocking=True)
+            if self.prev_metas is not None:
+                for i, m in enumerate(metas["img_metas"]):
+                    t = m["T_global_inv"] @ self.prev_metas["img_metas"][i]["T_global"]
+                    self.pin_t[i] = torch.from_numpy(np.asarray(t, np.float32))
+                    self.pin_dt[i] = float(m["timestamp"] - self.prev_metas["img_metas"][i]["timestamp"])
+                self.t_buf.copy_(self.pin_t, non_blocking=True)
+                self.dt_buf.copy_(self.pin_dt, non_blocking=True)
+
+    @torch.no_grad()
+    def step(self, img, metas, force_eager=False):
+        """Feed frame t; returns the detections of frame t-1 (None on the very first call)."""
+        slot = self.count % 2
+        cur = torch.cuda.current_stream()
+        self.s_bb.wait_stream(cur)
+        self.s_head.wait_stream(cur)
+        with torch.cuda.stream(self.s_bb):
+            self.imgs[slot].copy_(img, non_blocking=True)
+        self._run_backbone(slot, force_eager)
+        results = None
+        if self.pending is not None:
+            pslot, pmetas = self.pending
+            self._stage_head_inputs(pmetas)
+            warm = self.prev_metas is not None
+            rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"], warm, force_eager)
+            results = self._finish(rec, pmetas)
+        self.s_bb.synchronize()
+        self.pending = (slot, metas)
+        self.count += 1
+        return results
+
+    @torch.no_grad()
+    def flush(self):
+        """Run the decoder of the last fed frame and return its detections."""
+        if self.pending is None:
+            return None
+        pslot, pmetas = self.pending
+        self._stage_head_inputs(pmetas)
+        rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"],
+                             self.prev_metas is not None, True)
+        self.pending = None
+        return self._finish(rec, pmetas)
