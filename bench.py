@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--image-wh", type=int, nargs=2, default=(704, 256))
     ap.add_argument("--capacity", type=int, default=1536, help="static 2D query slots (N2 is ~1.1-1.2k at R50 704x256)")
     ap.add_argument("--eager", action="store_true", help="do not replay the frame as a hipGraph")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap backbone(t+1) with decoder(t) (simpb_amd.runner.PipelinedRunner)")
     ap.add_argument("--meter-frames", type=int, default=8, help="instrumented eager frames for the roofline leg")
     ap.add_argument("--no-conv-search", action="store_true",
                     help="do not let MIOpen benchmark convolution algorithms during warm-up (cudnn.benchmark off)")
@@ -200,20 +202,24 @@ def main():
     torch.set_num_threads(max(1, min(4, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
 
     from simpb_amd.dist import gather_detections, pack_detections
-    from simpb_amd.runner import FrameRunner
+    from simpb_amd.runner import FrameRunner, PipelinedRunner
     torch.backends.cudnn.benchmark = not args.no_conv_search
     model = build_model(args, device)
     total = args.warmup + args.steps + args.meter_frames
     imgs = make_frames(args, device, total)
     metas = [frame_metas(args, f) for f in range(total)]  # what a dataloader would hand over
-    runner = FrameRunner(model, args.bs, (args.image_wh[1], args.image_wh[0]), capacity=args.capacity, device=device,
-                         use_graph=not args.eager)
+    pipelined = not args.no_pipeline and not args.eager
+    runner = (PipelinedRunner if pipelined else FrameRunner)(
+        model, args.bs, (args.image_wh[1], args.image_wh[0]), capacity=args.capacity, device=device,
+        use_graph=not args.eager)
     gathered = None
     side = torch.cuda.Stream(device=device)
 
     def step(f, force_eager=False):
         nonlocal gathered
         results = runner.step(imgs[f % len(imgs)], metas[f], force_eager=force_eager)
+        if results is None:  # pipelined runner, very first call: nothing decoded yet
+            return None
         if dist is not None:  # detections of every stream to every rank, off the compute stream
             if args.backend == "nccl":
                 rec = pack_detections(results, device)
@@ -259,7 +265,8 @@ def main():
     if rank == 0:
         frames = world * args.bs * args.steps
         n2 = [int(x) for x in model.head.layers[0].last.count.sum(dim=1).tolist()] if model.head.layers[0].last else None
-        mode = dict(runner.stats, hipgraph=not args.eager, capacity_2d=args.capacity)
+        mode = dict(runner.stats, hipgraph=not args.eager, capacity_2d=args.capacity,
+                    pipelined_backbone=pipelined)
         def pmc_traffic(kernel):
             """HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside
             this process); None when no profile of this kernel is committed."""
