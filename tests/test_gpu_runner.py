@@ -112,7 +112,9 @@ def test_pipelined_runner_vs_golden():
 
 
 def test_pipelined_equals_plain_runner_with_real_backbone():
-    """Whole detector (ResNet50+FPN fp16 with folded BN + decoder), 12 frames: the pipelined runner
+    """Whole detector (ResNet50+FPN with folded BN, kept in fp32 here so that runs are comparable to
+    1e-3: fp16 convolutions differ run to run by more than that once random-weight heads amplify
+    them) + decoder, 12 frames: the pipelined runner
     (two streams, four graphs) returns what the plain graph runner returns, one step later, and the
     plain graph runner returns what the eager static path returns."""
     from simpb_amd import configs, plugin
@@ -123,7 +125,7 @@ def test_pipelined_equals_plain_runner_with_real_backbone():
         cfg = configs.simpb_plus(anchor=synth.anchors(900))
         model = plugin.build_detector(cfg["model"]).eval()
         synth.load_procedural(model)
-        return model.cuda().fuse_conv_bn().half_backbone()
+        return model.cuda().fuse_conv_bn()
 
     frames = 12
     imgs = [synth.images(1, f % 4, wh).cuda() for f in range(frames)]
