@@ -103,7 +103,8 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
         return value
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, query_cam=None, **kwargs):
+                reference_points=None, spatial_shapes=None, level_start_index=None, query_cam=None,
+                value_is_projected=False, **kwargs):
         if value is None:
             value = query
         if identity is None:
@@ -114,10 +115,13 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
             query = query.permute(1, 0, 2)
             value = value.permute(1, 0, 2)
         bs, num_query, _ = query.shape
-        bcs, num_value, _ = value.shape
-        assert bcs // self.num_cams == bs
-        value = self.project_value(value, key_padding_mask)
-        value = value.view(bs, self.num_cams, num_value, self.num_heads, -1)
+        if value_is_projected:  # project_value() was already applied by the caller (head.precompute_values)
+            num_value = value.shape[-2] if value.dim() == 3 and value.shape[0] == bs * self.num_cams else value.numel() // (bs * self.num_cams * self.embed_dims)
+        else:
+            bcs, num_value, _ = value.shape
+            assert bcs // self.num_cams == bs
+            value = self.project_value(value, key_padding_mask)
+        value = value.reshape(bs, self.num_cams, num_value, self.num_heads, -1)
         sampling_offsets = self.sampling_offsets(query).view(
             bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
         attention_weights = self.attention_weights(query).view(

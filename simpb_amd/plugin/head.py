@@ -144,6 +144,18 @@ class SimPBHead(BaseModule):
         }
         return encoder2d_dict, [col, ss32, st32]
 
+    def precompute_values(self, feature_maps):
+        """value_proj of every qg_cross_attn layer (group_attn.py:176) applied to the token buffer.
+        It depends on nothing but the features and the weights, so a caller that overlaps the
+        backbone of the next frame with this frame's decoder (runner.PipelinedRunner) runs it with the
+        backbone, off the decoder's critical path. Returns {layer index: projected tokens}."""
+        col = feature_maps[0]
+        out = {}
+        for i, op in enumerate(self.operation_order):
+            if op == "qg_cross_attn":
+                out[i] = self.layers[i].project_value(col)
+        return out
+
     # ------------------------------------------------------------------ decoupled attention
     def graph_model(self, index, query, key=None, value=None, query_pos=None, key_pos=None, **kwargs):
         """simpb_head.py:298-310."""
@@ -184,6 +196,7 @@ class SimPBHead(BaseModule):
         alloc_list = []
         cap = self.static_capacity
         temp_attn_instance = instance_feature
+        pre_values = feature_maps[3] if len(feature_maps) > 3 else None
         encoder2d_dict, feature_maps = self.prepare2d(feature_maps, metas)
         alloc = None
         last = len(self.operation_order) - 1
@@ -215,9 +228,12 @@ class SimPBHead(BaseModule):
                                                       query_pos=anchor_embed2d, query_groups=ref_query_groups,
                                                       query_cam=alloc.query_cam, group_start=alloc.group_start)
             elif op == "qg_cross_attn":
+                enc = encoder2d_dict
+                if pre_values is not None and i in pre_values:
+                    enc = dict(encoder2d_dict, value=pre_values[i], value_is_projected=True)
                 instance_feature = layer(query=instance_feature, query_pos=anchor_embed2d,
                                          reference_points=anchor2d.unsqueeze(2), query_groups=ref_query_groups,
-                                         query_cam=alloc.query_cam, **encoder2d_dict)
+                                         query_cam=alloc.query_cam, **enc)
             elif op == "refine2d":
                 anchor2d, cls2d, depth2d, alpha2d = layer(instance_feature, anchor2d, anchor_embed2d, metas=metas,
                                                           query_groups=ref_query_groups)

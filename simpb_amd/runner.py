@@ -158,7 +158,7 @@ class PipelinedRunner(FrameRunner):
                 self.s_bb.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=self.s_bb):
-                    self.bb_out[slot] = self.model.extract_feat(self.imgs[slot])
+                    self.bb_out[slot] = self._features(slot)
                 self.bb_graph[slot] = g
                 self.head_graph[slot] = None  # a decoder graph bound to the old buffer is stale
                 self.head_runs[slot] = 0
@@ -166,8 +166,16 @@ class PipelinedRunner(FrameRunner):
                 self.bb_graph[slot].replay()
                 self.fm[slot] = self.bb_out[slot]
             else:
-                self.fm[slot] = self.model.extract_feat(self.imgs[slot])
+                self.fm[slot] = self._features(slot)
             self.bb_runs[slot] += 1
+
+    def _features(self, slot):
+        """Backbone + FPN + token format, plus everything of the decoder that depends on the features
+        alone: the value projections of the three 2D cross-attention layers."""
+        fm = list(self.model.extract_feat(self.imgs[slot]))
+        if hasattr(self.head, "precompute_values") and len(fm) == 3:
+            fm.append(self.head.precompute_values(fm))
+        return fm
 
     def _decode(self, fm, dmetas, aug):
         outs = self.head(fm, dmetas)
