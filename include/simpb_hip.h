@@ -77,6 +77,15 @@ int simpb_ms_deform_attn_grouped_forward(
 int simpb_linear_f32(float* y, const float* x, const float* weight, const float* bias, int M, int N, int K,
                      int relu, void* stream);
 
+/* Forward direction of feature_maps_format (ops/__init__.py:63-92) in one pass. Level l is
+ * [num_images = bs*cams, H_l, W_l, channels] in memory (what a channels_last backbone emits), f16
+ * (src_is_half) or f32; level_ptrs/level_hw are HOST arrays of num_levels device pointers / H_l*W_l.
+ * col_feats f32 [bs, cams * sum_l H_l*W_l, channels], camera-major then level then row-major, as
+ * ops/src/deformable_aggregation.cpp:22-28 expects. channels % 8 == 0. */
+#define SIMPB_MAX_LEVELS 8
+int simpb_format_tokens(float* col_feats, const void* const* level_ptrs, const int* level_hw, int num_levels,
+                        int num_images, int channels, int src_is_half, void* stream);
+
 /* Attention core of torch.nn.MultiheadAttention (between in_proj and out_proj), exact fp32, flash
  * style, head_dim = 64: out[b,q,h*64+d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d].
  * q/k/v/out are [batch, N, heads*64] with row strides ldq/ldk/ldv/ldo (floats; batches are N*ld apart),

@@ -1,0 +1,83 @@
+// feature_maps_format (gfx950): FPN outputs -> the channel-last token buffer of the decoder.
+//
+// Replaces the forward direction of feature_maps_format
+// (/root/reference/projects/mmdet3d_plugin/ops/__init__.py:63-92: reshape + cat + permute + flatten,
+// i.e. three full copies of the 92 MB feature set per frame on top of the fp16->fp32 casts) with ONE
+// pass: the backbone runs channels_last, so a level is already [bs*cams, H, W, C] in memory and a
+// token row is C contiguous values; each row is converted (fp16 -> fp32 if needed) and written once
+// at its place in col_feats [bs, cam-major / level / row-major tokens, C].
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "../../include/simpb_hip.h"
+
+extern "C" int simpb_check_launch(void);
+
+namespace {
+
+struct LevelArgs {
+  const void* src[SIMPB_MAX_LEVELS];
+  int hw[SIMPB_MAX_LEVELS];       // H*W of each level
+  int start[SIMPB_MAX_LEVELS];    // token offset of each level inside one camera's block
+};
+
+// thread = 8 channels of one token; grid.y = level
+template <typename T>
+__global__ void format_tokens_kernel(float* __restrict__ col, LevelArgs lv, int images, int C, int tokens_per_cam) {
+  const int lvl = blockIdx.y;
+  const int hw = lv.hw[lvl];
+  const int c8 = C / 8;
+  const long long n = (long long)images * hw * c8;
+  const T* __restrict__ src = static_cast<const T*>(lv.src[lvl]);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8) * 8;
+    const long long tok = i / c8;            // image * hw + pixel
+    const int img = (int)(tok / hw), pix = (int)(tok - (long long)img * hw);
+    const T* s = src + tok * C + c;
+    float v[8];
+    if constexpr (sizeof(T) == 2) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(s);
+      const __half2* h2 = reinterpret_cast<const __half2*>(&raw);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float2 f = __half22float2(h2[j]);
+        v[2 * j] = f.x; v[2 * j + 1] = f.y;
+      }
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    float* d = col + ((long long)img * tokens_per_cam + lv.start[lvl] + pix) * C + c;
+    *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+}  // namespace
+
+extern "C" int simpb_format_tokens(float* col_feats, const void* const* level_ptrs, const int* level_hw, int num_levels,
+                                   int num_images, int channels, int src_is_half, void* stream) {
+  if (!col_feats || !level_ptrs || !level_hw || num_levels <= 0 || num_levels > SIMPB_MAX_LEVELS || num_images <= 0 ||
+      channels <= 0 || channels % 8 != 0)
+    return SIMPB_EINVAL;
+  LevelArgs lv;
+  int total = 0, max_hw = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    if (!level_ptrs[l] || level_hw[l] <= 0) return SIMPB_EINVAL;
+    lv.src[l] = level_ptrs[l];
+    lv.hw[l] = level_hw[l];
+    lv.start[l] = total;
+    total += level_hw[l];
+    max_hw = level_hw[l] > max_hw ? level_hw[l] : max_hw;
+  }
+  (void)hipGetLastError();
+  const long long n = (long long)num_images * max_hw * (channels / 8);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  dim3 grid(blocks, num_levels);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (src_is_half)
+    hipLaunchKernelGGL(format_tokens_kernel<__half>, grid, dim3(256), 0, s, col_feats, lv, num_images, channels, total);
+  else
+    hipLaunchKernelGGL(format_tokens_kernel<float>, grid, dim3(256), 0, s, col_feats, lv, num_images, channels, total);
+  return simpb_check_launch();
+}

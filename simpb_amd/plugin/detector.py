@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .layers import BaseModule
-from .ops import feature_maps_format
+from .ops import feature_maps_format, format_tokens
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS, PLUGIN_LAYERS, build_from_cfg
 
 __all__ = ["SimPB", "ResNet", "FPN"]
@@ -193,6 +193,9 @@ class SimPB(BaseModule):
         feature_maps = self.img_backbone(img)
         if self.img_neck is not None:
             feature_maps = list(self.img_neck(feature_maps))
+        if feature_maps[0].is_cuda and feature_maps[0].shape[1] % 8 == 0:
+            # channels_last maps are already token-major in memory: one conversion pass into col_feats
+            return format_tokens(feature_maps, bs, num_cams)
         feature_maps = [f.float() if self.fp16_enabled else f for f in feature_maps]
         feature_maps = [torch.reshape(f, (bs, num_cams) + f.shape[1:]) for f in feature_maps]
         return feature_maps_format(feature_maps)

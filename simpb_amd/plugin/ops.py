@@ -240,3 +240,31 @@ def attention_f32(q, k, v, num_heads, query_cam=None, group_start=None):
         1.0 / (hd ** 0.5), _stream())
     _lib.check(status, "simpb_attention_f32")
     return out
+
+
+def format_tokens(levels, bs, num_cams):
+    """feature_maps_format for channels_last level tensors [bs*cams, C, H, W] (f16 or f32), one
+    pass (csrc/format.hip). Returns [col_feats, spatial_shape, scale_start_index] like
+    feature_maps_format."""
+    _require_gpu(*levels)
+    c = levels[0].shape[1]
+    dtype = levels[0].dtype
+    shapes = tuple(tuple(f.shape[-2:]) for f in levels)
+    srcs = []
+    for f in levels:
+        if f.shape[0] != bs * num_cams or f.shape[1] != c or f.dtype != dtype:
+            raise ValueError("levels must share batch, channels and dtype")
+        if not f.is_contiguous(memory_format=torch.channels_last):
+            f = f.contiguous(memory_format=torch.channels_last)
+        srcs.append(f)
+    if dtype not in (torch.float16, torch.float32) or c % 8:
+        raise ValueError("format_tokens takes f16/f32 levels with channels % 8 == 0")
+    tokens = sum(h * w for h, w in shapes)
+    col = torch.empty(bs, num_cams * tokens, c, device=levels[0].device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * len(srcs))(*[f.data_ptr() for f in srcs])
+    hws = (ctypes.c_int * len(srcs))(*[h * w for h, w in shapes])
+    status = _lib.lib().simpb_format_tokens(_ptr(col), ptrs, hws, len(srcs), bs * num_cams, c,
+                                            1 if dtype == torch.float16 else 0, _stream())
+    _lib.check(status, "simpb_format_tokens")
+    spatial_shape, scale_start_index = _shape_tables(shapes, num_cams, col.device)
+    return [col, spatial_shape, scale_start_index]

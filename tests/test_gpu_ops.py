@@ -247,3 +247,15 @@ def test_attention_f32_grouped_with_pads_and_strided_views():
     want = want.transpose(1, 2).reshape(bs, n, 512)
     assert float((got.double() - want).abs().max()) < 2e-5
     assert float(got[:, 140:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_format_tokens_vs_feature_maps_format(dtype):
+    """One-pass token format against feature_maps_format (itself pinned by ops.npz:fmt.*)."""
+    ops = _ops()
+    bs, cams, c = 2, 6, 16
+    shapes = [(8, 22), (4, 11), (2, 6), (1, 3)]
+    maps = [torch.from_numpy(synth.randn(f"fmt2.l{l}", (bs * cams, c, h, w))).to(dtype).cuda() for l, (h, w) in enumerate(shapes)]
+    want = ops.feature_maps_format([m.float().reshape(bs, cams, c, *m.shape[-2:]) for m in maps])
+    got = ops.format_tokens([m.contiguous(memory_format=torch.channels_last) for m in maps], bs, cams)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
