@@ -52,6 +52,20 @@ int simpb_deformable_aggregation_forward(
     int batch_size, int num_cams, int num_feat, int num_embeds, int num_scale,
     int num_anchors, int num_pts, int num_groups, void* stream);
 
+/* Replaces `deformable_aggregation_grad(...)` (ops/src/deformable_aggregation.cpp:64-84, launcher
+ * ops/src/deformable_aggregation_cuda.cu:291-318, kernels :62-126,190-262), the backward of the
+ * operator (ops/deformable_aggregation.py:39-75). Layouts as the forward; grad_output f32
+ * [batch_size, num_anchors, num_embeds]. All three gradients are fully written (the callee clears
+ * grad_mc_ms_feat itself; the caller need not pre-zero anything). grad_weights and
+ * grad_sampling_location are deterministic; grad_mc_ms_feat is accumulated with float atomics.
+ * Supported layout: num_embeds % 64 == 0, num_embeds <= 256, (num_embeds / num_groups) % 32 == 0,
+ * num_pts * num_cams <= 128 (the shipped 256 / 8 / 13 x 6); anything else returns SIMPB_EINVAL. */
+int simpb_deformable_aggregation_backward(
+    float* grad_mc_ms_feat, float* grad_sampling_location, float* grad_weights, const float* mc_ms_feat,
+    const int* spatial_shape, const int* scale_start_index, const float* sample_location, const float* weights,
+    const float* grad_output, int batch_size, int num_cams, int num_feat, int num_embeds, int num_scale,
+    int num_anchors, int num_pts, int num_groups, void* stream);
+
 /* Replaces the per-camera loop over mmcv's `ms_deform_attn_forward` in
  * QueryGroupMultiScaleDeformableAttention.forward (models/group_attn.py:222-235): ONE launch for
  * all camera groups. Sampling rule = mmcv's CUDA op = grid_sample(bilinear, zeros,

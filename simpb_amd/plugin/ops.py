@@ -45,8 +45,7 @@ def _check_layout(spatial_shape, scale_start_index, num_feat):
 
 
 class DeformableAggregationFunction(Function):
-    """ops/deformable_aggregation.py:7-37 (forward). The backward of the reference (:39-75) is
-    training-only and not part of this path yet."""
+    """ops/deformable_aggregation.py:7-75: forward and backward of the operator."""
 
     @staticmethod
     def forward(ctx, mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights):
@@ -75,11 +74,28 @@ class DeformableAggregationFunction(Function):
             _ptr(output), _ptr(mc_ms_feat), _ptr(spatial_shape), _ptr(scale_start_index), _ptr(sampling_location),
             _ptr(weights), bs, num_cams, num_feat, num_embeds, num_scale, num_anchors, num_pts, num_groups, _stream())
         _lib.check(status, "simpb_deformable_aggregation_forward")
+        if any(t.requires_grad for t in (mc_ms_feat, sampling_location, weights)):
+            ctx.save_for_backward(mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights)
         return output
 
     @staticmethod
     def backward(ctx, grad_output):
-        raise NotImplementedError("deformable_aggregation backward is not part of the inference hot path")
+        """ops/deformable_aggregation.py:39-75."""
+        mc_ms_feat, spatial_shape, scale_start_index, sampling_location, weights = ctx.saved_tensors
+        grad_output = grad_output.contiguous().float()
+        bs, num_feat, num_embeds = mc_ms_feat.shape
+        num_cams, num_scale = spatial_shape.shape[:2]
+        _, num_anchors, num_pts = sampling_location.shape[:3]
+        num_groups = weights.shape[5]
+        grad_feat = torch.empty_like(mc_ms_feat)
+        grad_loc = torch.empty_like(sampling_location)
+        grad_w = torch.empty_like(weights)
+        status = _lib.lib().simpb_deformable_aggregation_backward(
+            _ptr(grad_feat), _ptr(grad_loc), _ptr(grad_w), _ptr(mc_ms_feat), _ptr(spatial_shape), _ptr(scale_start_index),
+            _ptr(sampling_location), _ptr(weights), _ptr(grad_output), bs, num_cams, num_feat, num_embeds, num_scale,
+            num_anchors, num_pts, num_groups, _stream())
+        _lib.check(status, "simpb_deformable_aggregation_backward")
+        return grad_feat, None, None, grad_loc, grad_w
 
 
 def deformable_aggregation_function(feature_maps, spatial_shape, scale_start_index, sampling_location, weights):

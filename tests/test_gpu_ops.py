@@ -259,3 +259,28 @@ def test_format_tokens_vs_feature_maps_format(dtype):
     want = ops.feature_maps_format([m.float().reshape(bs, cams, c, *m.shape[-2:]) for m in maps])
     got = ops.format_tokens([m.contiguous(memory_format=torch.channels_last) for m in maps], bs, cams)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+
+
+@pytest.mark.parametrize("shape", [
+    dict(bs=2, A=23, P=13, K=6, L=4, G=8, C=256, maps=[(16, 44), (8, 22), (4, 11), (2, 6)]),  # shipped layout
+    dict(bs=1, A=7, P=3, K=2, L=2, G=2, C=128, maps=[(5, 7), (3, 2)]),                       # 64 channels per group
+])
+def test_daf_backward_vs_autograd_of_oracle(shape):
+    """Gradients of the HIP operator against torch autograd through the oracle's forward
+    (deformable_aggregation_cuda.cu:62-126,190-262 is the analytic form of the same derivative)."""
+    R = _oracle()
+    s = shape
+    rs = np.random.RandomState(11)
+    maps = [torch.from_numpy(rs.standard_normal((s["bs"], s["K"], s["C"], h, w)).astype(np.float32)) for h, w in s["maps"]]
+    col, ss, ssi = R.feature_maps_format(maps)
+    loc = torch.from_numpy(rs.uniform(-0.2, 1.2, (s["bs"], s["A"], s["P"], s["K"], 2)).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(0, 1, (s["bs"], s["A"], s["P"], s["K"], s["L"], s["G"])).astype(np.float32))
+    gout = torch.from_numpy(rs.standard_normal((s["bs"], s["A"], s["C"])).astype(np.float32))
+    c1, l1, w1 = col.clone().requires_grad_(), loc.clone().requires_grad_(), w.clone().requires_grad_()
+    R.deformable_aggregation(c1, ss.int(), ssi.int(), l1, w1).backward(gout)
+    c2, l2, w2 = (t.clone().cuda().requires_grad_() for t in (col, loc, w))
+    out = _ops().deformable_aggregation_function(c2, ss.int().cuda(), ssi.int().cuda(), l2, w2)
+    out.backward(gout.cuda())
+    for name, got, want in (("feat", c2.grad, c1.grad), ("loc", l2.grad, l1.grad), ("weights", w2.grad, w1.grad)):
+        scale = max(float(want.abs().max()), 1.0)
+        assert float((got.cpu() - want).abs().max()) <= 2e-4 * scale, name
