@@ -83,6 +83,16 @@ int simpb_ms_deform_attn_grouped_forward(
     int batch_size, int num_cams, int num_value, int num_heads, int channels,
     int num_levels, int num_points, int num_query, void* stream);
 
+/* Backward of simpb_ms_deform_attn_grouped_forward (what mmcv's ms_deform_attn_backward does per camera
+ * group behind models/group_attn.py:227-235). grad_output f32 [bs, num_query, heads*channels]; all three
+ * gradients are fully written (grad_value is cleared by the callee and accumulated with float atomics;
+ * the other two are deterministic). Supported layout: heads * channels == 256, channels/4 a power of two. */
+int simpb_ms_deform_attn_grouped_backward(
+    float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, const float* value,
+    const long long* spatial_shapes, const long long* level_start, const float* sampling_loc, const float* attn_weight,
+    const int* query_cam, const float* grad_output, int batch_size, int num_cams, int num_value, int num_heads,
+    int channels, int num_levels, int num_points, int num_query, void* stream);
+
 /* y[M, N] = x[M, K] . weight[N, K]^T + bias[N] (bias may be NULL), optional ReLU; exact fp32 on the
  * f32 matrix cores. Replaces nn.Linear where the reference runs it over every camera token:
  * value_proj in QueryGroupMultiScaleDeformableAttention.forward (models/group_attn.py:176), and the

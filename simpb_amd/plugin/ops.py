@@ -161,6 +161,39 @@ def query_cam_from_groups(query_groups, num_query, device):
     return cam.to(device)
 
 
+class MSDeformAttnGroupedFunction(Function):
+    """Grouped counterpart of mmcv's MultiScaleDeformableAttnFunction (forward + backward)."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, sampling_locations, attention_weights, query_cam):
+        bs, num_cams, num_value, heads, ch = value.shape
+        _, nq, _, lvls, pts, _ = sampling_locations.shape
+        output = torch.empty(bs, nq, heads * ch, device=value.device, dtype=torch.float32)
+        if nq:
+            status = _lib.lib().simpb_ms_deform_attn_grouped_forward(
+                _ptr(output), _ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_locations),
+                _ptr(attention_weights), _ptr(query_cam), bs, num_cams, num_value, heads, ch, lvls, pts, nq, _stream())
+            _lib.check(status, "simpb_ms_deform_attn_grouped_forward")
+        if any(t.requires_grad for t in (value, sampling_locations, attention_weights)):
+            ctx.save_for_backward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, query_cam)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        value, spatial_shapes, level_start_index, sampling_locations, attention_weights, query_cam = ctx.saved_tensors
+        bs, num_cams, num_value, heads, ch = value.shape
+        _, nq, _, lvls, pts, _ = sampling_locations.shape
+        g_value = torch.empty_like(value)
+        g_loc = torch.empty_like(sampling_locations)
+        g_attn = torch.empty_like(attention_weights)
+        status = _lib.lib().simpb_ms_deform_attn_grouped_backward(
+            _ptr(g_value), _ptr(g_loc), _ptr(g_attn), _ptr(value), _ptr(spatial_shapes), _ptr(level_start_index),
+            _ptr(sampling_locations), _ptr(attention_weights), _ptr(query_cam), _ptr(grad_output.contiguous().float()),
+            bs, num_cams, num_value, heads, ch, lvls, pts, nq, _stream())
+        _lib.check(status, "simpb_ms_deform_attn_grouped_backward")
+        return g_value, None, None, g_loc, g_attn, None
+
+
 def ms_deform_attn_grouped(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, query_cam):
     """One launch for what group_attn.py:227-235 does with a Python loop over cameras and
     MultiScaleDeformableAttnFunction.apply. value [bs, cam, Nv, heads, ch]; sampling_locations
@@ -186,14 +219,8 @@ def ms_deform_attn_grouped(value, spatial_shapes, level_start_index, sampling_lo
     if ch % 4 != 0:
         raise ValueError("channels per head must be a multiple of 4")
     _check_layout(spatial_shapes[None], level_start_index[None], num_value)
-    output = torch.empty(bs, nq, heads * ch, device=value.device, dtype=torch.float32)
-    if nq == 0:
-        return output
-    status = _lib.lib().simpb_ms_deform_attn_grouped_forward(
-        _ptr(output), _ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_locations),
-        _ptr(attention_weights), _ptr(query_cam), bs, num_cams, num_value, heads, ch, lvls, pts, nq, _stream())
-    _lib.check(status, "simpb_ms_deform_attn_grouped_forward")
-    return output
+    return MSDeformAttnGroupedFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
+                                             attention_weights, query_cam)
 
 
 def linear_f32(x, weight, bias=None, relu=False):

@@ -284,3 +284,23 @@ def test_daf_backward_vs_autograd_of_oracle(shape):
     for name, got, want in (("feat", c2.grad, c1.grad), ("loc", l2.grad, l1.grad), ("weights", w2.grad, w1.grad)):
         scale = max(float(want.abs().max()), 1.0)
         assert float((got.cpu() - want).abs().max()) <= 2e-4 * scale, name
+
+
+def test_msda_grouped_backward_vs_autograd_of_oracle():
+    """[parity unpinned: the sampler is mmcv's] gradients of the grouped HIP sampler against torch
+    autograd through the oracle's grid_sample formulation, per camera group."""
+    R = _oracle()
+    cfg = dict(bs=2, nq=41, heads=8, ch=32, shapes=[(8, 22), (4, 11), (2, 6), (1, 3)], pts=4, ncam=6)
+    value, ss, lsi, loc, aw, groups = _msda_inputs(seed=13, **cfg)
+    gout = torch.from_numpy(np.random.RandomState(14).standard_normal((cfg["bs"], cfg["nq"], 256)).astype(np.float32))
+    v1, l1, a1 = value.clone().requires_grad_(), loc.clone().requires_grad_(), aw.clone().requires_grad_()
+    outs = [R.ms_deform_attn(v1[:, i].contiguous(), ss, l1[:, s:e].contiguous(), a1[:, s:e].contiguous())
+            for i, (s, e) in enumerate(groups) if e > s]
+    torch.cat(outs, dim=1).backward(gout)
+    ops = _ops()
+    qcam = ops.query_cam_from_groups(groups, cfg["nq"], "cuda")
+    v2, l2, a2 = (t.clone().cuda().requires_grad_() for t in (value, loc, aw))
+    ops.ms_deform_attn_grouped(v2, ss.cuda(), lsi.cuda(), l2, a2, qcam).backward(gout.cuda())
+    for name, got, want in (("value", v2.grad, v1.grad), ("loc", l2.grad, l1.grad), ("attn", a2.grad, a1.grad)):
+        scale = max(float(want.abs().max()), 1.0)
+        assert float((got.cpu() - want).abs().max()) <= 2e-4 * scale, name
