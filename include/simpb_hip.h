@@ -126,7 +126,7 @@ int simpb_attention_f32(float* out, const float* q, const float* k, const float*
  * the same rows share it (e.g. the pos/size/yaw/vel branches of SparseBox3DEncoder,
  * models/detection3d/blocks.py:57-74). The argument block is a plain host struct of device
  * pointers and sizes. Every width <= 256.
- *   op LINEAR:    w = weight TRANSPOSED, f32 [in_dim, out_dim]; b = bias [out_dim] or NULL; relu 0/1
+ *   op LINEAR:    w = weight, f32 [out_dim, in_dim] (or transposed, see weights_transposed); b = bias [out_dim] or NULL; relu 0/1
  *   op LAYERNORM: w = gamma, b = beta, f32 [in_dim]; eps 1e-5
  *   chain input:  IN_ROWS    x f32 rows of in_dim values, row stride ldx (floats); optional second
  *                            addend x2 (row stride ldx2): input = x + x2
@@ -155,6 +155,8 @@ typedef struct simpb_mlp_chain {
 } simpb_mlp_chain;
 typedef struct simpb_mlp_args {
   int num_rows, num_chains;
+  int weights_transposed;  /* 1: LINEAR.w is [in_dim, out_dim] (VALU kernel); 0: nn.Linear's [out_dim, in_dim] (MFMA kernel) */
+  int reserved;
   simpb_mlp_chain chain[SIMPB_MLP_MAX_CHAINS];
 } simpb_mlp_args;
 int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream);

@@ -207,6 +207,167 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_chain_kernel(simpb_mlp_args ar
   }
 }
 
+
+// ---- matrix-core variant: 16 rows per workgroup, 8 waves; wave w owns output columns [32w, 32w+32)
+// of a Linear layer as two 16x16 tiles of v_mfma_f32_16x16x4_f32 (exact fp32). Operands use the
+// ORIGINAL weight layout [out][in]: with the k-order permuted (lane quarter kq takes k = 16*kq + s
+// inside each 64-wide k-chunk) a lane's 16 operand values are contiguous both in the weight row it
+// reads from L2 and in the activation row it reads from LDS, so they arrive as float4 loads; A and
+// B use the same permutation, so the sum is unchanged.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kMR = 16, kMW = 8;
+
+__global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args args) {
+  constexpr int kThreads = kMW * 64;
+  __shared__ float act[2][kMR][kMaxDim + 4];   // +4: rows 16 B apart in bank space for the b128 reads
+  const simpb_mlp_chain& ch = args.chain[blockIdx.y];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * kMR;
+  const int N = args.num_rows;
+
+  if (ch.in_mode == SIMPB_MLP_IN_SINE2D) {
+    for (int idx = tid; idx < kMR * 256; idx += kThreads) {
+      const int r = idx >> 8, j = idx & 255;
+      const int row = row0 + r;
+      float v = 0.f;
+      if (row < N) {
+        const int axis = j < 128 ? 1 : 0, i = j & 127;
+        const float coord = ch.x[(size_t)row * ch.ldx + axis] * 6.283185307179586f;
+        const float dim_t = powf(10000.f, (float)(2 * (i >> 1)) / 128.f);
+        const float p = coord / dim_t;
+        v = (i & 1) ? cosf(p) : sinf(p);
+      }
+      act[0][r][j] = v;
+    }
+  } else {
+    for (int idx = tid; idx < kMR * ch.in_dim; idx += kThreads) {
+      const int r = idx / ch.in_dim, k = idx - r * ch.in_dim;
+      const int row = row0 + r;
+      float v = 0.f;
+      if (row < N) {
+        v = ch.x[(size_t)row * ch.ldx + k];
+        if (ch.x2) v += ch.x2[(size_t)row * ch.ldx2 + k];
+      }
+      act[0][r][k] = v;
+    }
+  }
+  __syncthreads();
+
+  int cur = 0;
+  int width = ch.in_mode == SIMPB_MLP_IN_SINE2D ? 256 : ch.in_dim;
+  for (int o = 0; o < ch.n_ops; ++o) {
+    const simpb_mlp_op& op = ch.ops[o];
+    if (op.type == SIMPB_MLP_LINEAR) {
+      const int K = op.in_dim, D = op.out_dim;
+      if ((K & 63) == 0 && (D & 31) == 0) {
+        const int col0 = wave * 32;
+        if (col0 < D) {
+          const int r16 = lane & 15, kq = lane >> 4;
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          const float* w0 = op.w + (size_t)(col0 + r16) * K + 16 * kq;        // original layout [D][K]
+          const float* w1 = op.w + (size_t)(col0 + 16 + r16) * K + 16 * kq;
+          const float* ar = &act[cur][r16][16 * kq];
+          float4 b0[4], b1[4], nb0[4], nb1[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { b0[j] = *reinterpret_cast<const float4*>(w0 + 4 * j); b1[j] = *reinterpret_cast<const float4*>(w1 + 4 * j); }
+          for (int k0 = 0; k0 < K; k0 += 64) {
+            const bool more = k0 + 64 < K;
+            if (more) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                nb0[j] = *reinterpret_cast<const float4*>(w0 + k0 + 64 + 4 * j);
+                nb1[j] = *reinterpret_cast<const float4*>(w1 + k0 + 64 + 4 * j);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4 a = *reinterpret_cast<const float4*>(ar + k0 + 4 * j);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[j].x, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[j].x, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[j].y, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[j].y, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[j].z, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[j].z, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[j].w, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[j].w, acc1, 0, 0, 0);
+            }
+            if (more) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { b0[j] = nb0[j]; b1[j] = nb1[j]; }
+            }
+          }
+          // C/D of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
+          const int c0 = col0 + r16, c1 = col0 + 16 + r16;
+          const float bias0 = op.b ? op.b[c0] : 0.f, bias1 = op.b ? op.b[c1] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+            act[cur ^ 1][4 * kq + r][c0] = op.relu ? fmaxf(v0, 0.f) : v0;
+            act[cur ^ 1][4 * kq + r][c1] = op.relu ? fmaxf(v1, 0.f) : v1;
+          }
+        }
+      } else if (tid < D) {  // narrow / odd layers (K = 2, 3, 12, 32; D = 2..11): one thread per column
+        float acc[kMR];
+        const float b = op.b ? op.b[tid] : 0.f;
+#pragma unroll
+        for (int r = 0; r < kMR; ++r) acc[r] = b;
+        const float* wr = op.w + (size_t)tid * K;
+        for (int k = 0; k < K; ++k) {
+          const float wv = wr[k];
+#pragma unroll
+          for (int r = 0; r < kMR; ++r) acc[r] = fmaf(act[cur][r][k], wv, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < kMR; ++r) act[cur ^ 1][r][tid] = op.relu ? fmaxf(acc[r], 0.f) : acc[r];
+      }
+      __syncthreads();
+      cur ^= 1;
+      width = D;
+    } else {
+      const int D = op.in_dim;
+      for (int r = wave; r < kMR; r += kMW) {
+        float v[kMaxDim / 64];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxDim / 64; ++j) {
+          const int e = lane + 64 * j;
+          v[j] = e < D ? act[cur][r][e] : 0.f;
+          s += v[j];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        const float mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxDim / 64; ++j) {
+          const int e = lane + 64 * j;
+          const float d = e < D ? v[j] - mean : 0.f;
+          q += d * d;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+        const float inv = 1.f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < kMaxDim / 64; ++j) {
+          const int e = lane + 64 * j;
+          if (e < D) act[cur][r][e] = (v[j] - mean) * inv * op.w[e] + op.b[e];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int idx = tid; idx < kMR * width; idx += kThreads) {
+    const int r = idx / width, t = idx - r * width;
+    const int row = row0 + r;
+    if (row < N) {
+      float v = act[cur][r][t];
+      if (ch.out_scale) v *= ch.out_scale[t];
+      ch.out[(size_t)row * ch.ldo + t] = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream) {
@@ -231,10 +392,15 @@ extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream)
     }
   }
   (void)hipGetLastError();
-  // 4 rows x 8 waves: enough workgroups to occupy every CU at ~900-1500 rows, and 8 waves per CU
-  // keep 64 KiB of weight rows in flight
-  constexpr int R = 4, WAVES = 8;
-  dim3 grid((args->num_rows + R - 1) / R, args->num_chains);
-  hipLaunchKernelGGL((mlp_chain_kernel<R, WAVES>), grid, dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream), *args);
+  if (args->weights_transposed) {
+    // VALU variant (weights [in][out]): 4 rows x 8 waves, split-K with 16-byte weight loads
+    constexpr int R = 4, WAVES = 8;
+    dim3 grid((args->num_rows + R - 1) / R, args->num_chains);
+    hipLaunchKernelGGL((mlp_chain_kernel<R, WAVES>), grid, dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream), *args);
+  } else {
+    // matrix-core variant (weights in nn.Linear's own [out][in] layout): 16 rows x 8 waves
+    dim3 grid((args->num_rows + kMR - 1) / kMR, args->num_chains);
+    hipLaunchKernelGGL(mlp_chain_mfma_kernel, grid, dim3(kMW * 64), 0, static_cast<hipStream_t>(stream), *args);
+  }
   return simpb_check_launch();
 }

@@ -12,6 +12,7 @@ from .layers import Scale
 from .ops import _stream
 
 MAX_OPS, MAX_CHAINS = 12, 4
+TRANSPOSED_WEIGHTS = False  # False: matrix-core kernel on the weights as stored; True: VALU kernel on transposed copies
 LINEAR, LAYERNORM = 0, 1
 IN_ROWS, IN_SINE2D = 0, 1
 
@@ -28,7 +29,8 @@ class _Chain(ctypes.Structure):
 
 
 class _Args(ctypes.Structure):
-    _fields_ = [("num_rows", ctypes.c_int), ("num_chains", ctypes.c_int), ("chain", _Chain * MAX_CHAINS)]
+    _fields_ = [("num_rows", ctypes.c_int), ("num_chains", ctypes.c_int), ("weights_transposed", ctypes.c_int),
+                ("reserved", ctypes.c_int), ("chain", _Chain * MAX_CHAINS)]
 
 
 class ChainPlan:
@@ -78,9 +80,15 @@ class ChainPlan:
             op = chain.ops[j]
             op.type, op.in_dim, op.out_dim, op.relu = typ, din, dout, relu
             if typ == LINEAR:
-                wt = self._transposed(m)
-                keep.append(wt)
-                op.w = wt.data_ptr()
+                if TRANSPOSED_WEIGHTS:
+                    wt = self._transposed(m)
+                    keep.append(wt)
+                    op.w = wt.data_ptr()
+                else:
+                    w = m.weight
+                    if not w.is_contiguous() or w.dtype != torch.float32:
+                        raise ValueError("mlp_chain reads nn.Linear weights in place: contiguous f32 expected")
+                    op.w = w.data_ptr()
                 op.b = m.bias.data_ptr() if m.bias is not None else None
             else:
                 op.w, op.b = m.weight.data_ptr(), m.bias.data_ptr()
@@ -116,6 +124,7 @@ def run_chains(jobs, num_rows, device):
         raise ValueError("1..4 chains per launch")
     args = _Args()
     args.num_rows, args.num_chains = int(num_rows), len(jobs)
+    args.weights_transposed = 1 if TRANSPOSED_WEIGHTS else 0
     keep = []
     for c, job in enumerate(jobs):
         ch = args.chain[c]
