@@ -260,13 +260,15 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
     const simpb_mlp_op& op = ch.ops[o];
     if (op.type == SIMPB_MLP_LINEAR) {
       const int K = op.in_dim, D = op.out_dim;
-      if ((K & 63) == 0 && (D & 31) == 0) {
+      if ((K & 63) == 0) {  // any D: columns past D are fed zeros and not stored (D = 2..11 heads use wave 0 only)
         const int col0 = wave * 32;
         if (col0 < D) {
           const int r16 = lane & 15, kq = lane >> 4;
+          const bool cv0 = col0 + r16 < D, cv1 = col0 + 16 + r16 < D;
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-          const float* w0 = op.w + (size_t)(col0 + r16) * K + 16 * kq;        // original layout [D][K]
-          const float* w1 = op.w + (size_t)(col0 + 16 + r16) * K + 16 * kq;
+          const float* w0 = op.w + (size_t)(cv0 ? col0 + r16 : 0) * K + 16 * kq;        // original layout [D][K]
+          const float* w1 = op.w + (size_t)(cv1 ? col0 + 16 + r16 : 0) * K + 16 * kq;
+          const float m0 = cv0 ? 1.f : 0.f, m1 = cv1 ? 1.f : 0.f;
           const float* ar = &act[cur][r16][16 * kq];
           float4 b0[4], b1[4], nb0[4], nb1[4];
 #pragma unroll
@@ -283,14 +285,14 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float4 a = *reinterpret_cast<const float4*>(ar + k0 + 4 * j);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[j].x, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[j].x, acc1, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[j].y, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[j].y, acc1, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[j].z, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[j].z, acc1, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[j].w, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[j].w, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[j].x * m0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[j].x * m1, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[j].y * m0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[j].y * m1, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[j].z * m0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[j].z * m1, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[j].w * m0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[j].w * m1, acc1, 0, 0, 0);
             }
             if (more) {
 #pragma unroll
@@ -299,12 +301,12 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
           }
           // C/D of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
           const int c0 = col0 + r16, c1 = col0 + 16 + r16;
-          const float bias0 = op.b ? op.b[c0] : 0.f, bias1 = op.b ? op.b[c1] : 0.f;
+          const float bias0 = (op.b && cv0) ? op.b[c0] : 0.f, bias1 = (op.b && cv1) ? op.b[c1] : 0.f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-            act[cur ^ 1][4 * kq + r][c0] = op.relu ? fmaxf(v0, 0.f) : v0;
-            act[cur ^ 1][4 * kq + r][c1] = op.relu ? fmaxf(v1, 0.f) : v1;
+            if (cv0) act[cur ^ 1][4 * kq + r][c0] = op.relu ? fmaxf(v0, 0.f) : v0;
+            if (cv1) act[cur ^ 1][4 * kq + r][c1] = op.relu ? fmaxf(v1, 0.f) : v1;
           }
         }
       } else if (tid < D) {  // narrow / odd layers (K = 2, 3, 12, 32; D = 2..11): one thread per column
