@@ -110,6 +110,12 @@ int simpb_linear_f32(float* y, const float* x, const float* weight, const float*
 int simpb_format_tokens(float* col_feats, const void* const* level_ptrs, const int* level_hw, int num_levels,
                         int num_images, int channels, int src_is_half, void* stream);
 
+/* Backbone convolution epilogue after conv-BN folding (tools/fuse_conv_bn.py:10-48): in place,
+ * y f16 [num_pixels, channels] (NHWC) = relu?(y + bias[c] + residual?). bias f16 [channels]; residual f16
+ * like y or NULL; channels % 8 == 0; all pointers 16-byte aligned. */
+int simpb_bias_act_nhwc_f16(void* y, const void* bias, const void* residual, long long num_pixels, int channels,
+                            int relu, void* stream);
+
 /* Attention core of torch.nn.MultiheadAttention (between in_proj and out_proj), exact fp32, flash
  * style, head_dim = 64: out[b,q,h*64+d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d].
  * q/k/v/out are [batch, N, heads*64] with row strides ldq/ldk/ldv/ldo (floats; batches are N*ld apart),

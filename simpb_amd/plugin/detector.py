@@ -33,11 +33,29 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if getattr(self, "fused_epilogue", False) and x.is_cuda and x.dtype == torch.float16:
+            return self._forward_fused(x)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
         return self.relu(out + identity)
+
+    def _forward_fused(self, x):
+        """BN already folded (SimPB.fuse_conv_bn): convolutions run without bias and each is followed
+        by ONE epilogue kernel (bias [+ residual] [+ ReLU]) instead of add_, add and relu_."""
+        from .ops import bias_act_
+
+        def conv(m, t):
+            return F.conv2d(t, m.weight, None, m.stride, m.padding)
+
+        if self.downsample is None:
+            identity = x
+        else:
+            identity = bias_act_(conv(self.downsample[0], x), self.downsample[0].bias, None, relu=False)
+        out = bias_act_(conv(self.conv1, x), self.conv1.bias, None, relu=True)
+        out = bias_act_(conv(self.conv2, out), self.conv2.bias, None, relu=True)
+        return bias_act_(conv(self.conv3, out), self.conv3.bias, identity, relu=True)
 
 
 @BACKBONES.register_module()
@@ -75,7 +93,13 @@ class ResNet(BaseModule):
             self.res_layers.append(name)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        if getattr(self, "fused_epilogue", False) and x.is_cuda and x.dtype == torch.float16:
+            from .ops import bias_act_
+            x = bias_act_(F.conv2d(x, self.conv1.weight, None, self.conv1.stride, self.conv1.padding), self.conv1.bias,
+                          None, relu=True)
+            x = self.maxpool(x)
+        else:
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)
@@ -178,6 +202,11 @@ class SimPB(BaseModule):
         if self.img_neck is not None:
             self.img_neck.half().to(memory_format=torch.channels_last)
         self.fp16_enabled = True
+        if isinstance(self.img_backbone.bn1, nn.Identity):  # BN folded: use the one-kernel conv epilogue
+            self.img_backbone.fused_epilogue = True
+            for name in self.img_backbone.res_layers:
+                for blk in getattr(self.img_backbone, name):
+                    blk.fused_epilogue = True
         return self
 
     def extract_feat(self, img, return_depth=False, metas=None):

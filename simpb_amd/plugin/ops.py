@@ -311,3 +311,20 @@ def format_tokens(levels, bs, num_cams):
     _lib.check(status, "simpb_format_tokens")
     spatial_shape, scale_start_index = _shape_tables(shapes, num_cams, col.device)
     return [col, spatial_shape, scale_start_index]
+
+
+def bias_act_(y, bias, residual=None, relu=True):
+    """In place y = relu?(y + bias[c] + residual?) for a channels_last f16 tensor [N, C, H, W]
+    (csrc/bias_act.hip): the epilogue of a BN-folded convolution in one pass."""
+    _require_gpu(y, bias)
+    n, c, h, w = y.shape
+    if (y.dtype != torch.float16 or not y.is_contiguous(memory_format=torch.channels_last) or bias.dtype != torch.float16
+            or bias.numel() != c or c % 8):
+        raise ValueError("bias_act_ takes a channels_last f16 tensor and an f16 bias with channels % 8 == 0")
+    if residual is not None and (residual.shape != y.shape or residual.dtype != torch.float16
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError("residual must match y (channels_last f16)")
+    status = _lib.lib().simpb_bias_act_nhwc_f16(_ptr(y), _ptr(bias), _ptr(residual) if residual is not None else None,
+                                                n * h * w, c, 1 if relu else 0, _stream())
+    _lib.check(status, "simpb_bias_act_nhwc_f16")
+    return y

@@ -304,3 +304,25 @@ def test_msda_grouped_backward_vs_autograd_of_oracle():
     for name, got, want in (("value", v2.grad, v1.grad), ("loc", l2.grad, l1.grad), ("attn", a2.grad, a1.grad)):
         scale = max(float(want.abs().max()), 1.0)
         assert float((got.cpu() - want).abs().max()) <= 2e-4 * scale, name
+
+
+def test_fused_backbone_epilogue_matches_plain_fp16_backbone():
+    """ResNet50+FPN fp16 with folded BN: the one-kernel conv epilogue (bias [+residual] [+ReLU]) against
+    the same folded network run with PyTorch's add_/add/relu_. Both are fp16; the fused epilogue rounds
+    once instead of up to three times, hence the fp16-level tolerance."""
+    from simpb_amd import configs, plugin
+    cfg = configs.simpb_plus(anchor=synth.anchors(900))
+    model = plugin.build_detector(cfg["model"]).eval()
+    synth.load_procedural(model)
+    model = model.cuda().fuse_conv_bn().half_backbone()
+    img = synth.images(1, 0, (352, 128)).cuda()
+    with torch.no_grad():
+        got = model.extract_feat(img)[0]
+        model.img_backbone.fused_epilogue = False
+        for name in model.img_backbone.res_layers:
+            for blk in getattr(model.img_backbone, name):
+                blk.fused_epilogue = False
+        want = model.extract_feat(img)[0]
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-2 * scale
+    assert float((got - want).abs().mean()) <= 2e-3 * scale
