@@ -82,25 +82,42 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
   const float* kbase = k + (size_t)b * Nk * ldk + head * kHD;
   const float* vbase = v + (size_t)b * Nk * ldv + head * kHD;
 
-  for (int kt = kb + 32 * wave; kt < ke; kt += 32 * kWaves) {
+  // K tile of this wave's first key tile; inside the loop the NEXT tile's K rows and the CURRENT tile's
+  // V values are requested before the matrix work that does not need them, so their latency hides
+  // behind the S^T product and the softmax (nothing else overlaps it at 2 waves per SIMD).
+  auto load_k = [&](int kt, float (&kreg)[32]) {
+    const int kk = kt + qi;
+    const bool k_ok = kk < ke;
+    const float* kp = kbase + (size_t)(k_ok ? kk : kb) * ldk + 32 * half;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(kp + 4 * j);
+      kreg[4 * j + 0] = k_ok ? t.x : 0.f; kreg[4 * j + 1] = k_ok ? t.y : 0.f;
+      kreg[4 * j + 2] = k_ok ? t.z : 0.f; kreg[4 * j + 3] = k_ok ? t.w : 0.f;
+    }
+  };
+  float kcur[32], knext[32];
+  const int kt0 = kb + 32 * wave;
+  if (kt0 < ke) load_k(kt0, kcur);
+  for (int kt = kt0; kt < ke; kt += 32 * kWaves) {
+    // V values of this tile: lane (d, half) holds V[key kt + acc_row(s, half)][d], s = 0..15
+    float va0[16], va1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int kidx = kt + acc_row(s, half);
+      const bool k_ok = kidx < ke;
+      const float* vp = vbase + (size_t)(k_ok ? kidx : kb) * ldv + qi;
+      va0[s] = k_ok ? vp[0] : 0.f;
+      va1[s] = k_ok ? vp[32] : 0.f;
+    }
+    const int ktn = kt + 32 * kWaves;
+    if (ktn < ke) load_k(ktn, knext);
     // ---- S^T tile = K_tile . Q^T  (A: lane (key, half) holds K[key][32*half + s])
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
-    {
-      const int kk = kt + qi;
-      const bool k_ok = kk < ke;
-      const float* kp = kbase + (size_t)(k_ok ? kk : kb) * ldk + 32 * half;
-      float kreg[32];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 t = *reinterpret_cast<const float4*>(kp + 4 * j);
-        kreg[4 * j + 0] = k_ok ? t.x : 0.f; kreg[4 * j + 1] = k_ok ? t.y : 0.f;
-        kreg[4 * j + 2] = k_ok ? t.z : 0.f; kreg[4 * j + 3] = k_ok ? t.w : 0.f;
-      }
-#pragma unroll
-      for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s], qreg[s], st, 0, 0, 0);
-    }
+    for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kcur[s], qreg[s], st, 0, 0, 0);
     // ---- mask + online softmax; this lane: query qi, keys kt + acc_row(r, half)
     float mt = -INFINITY;
 #pragma unroll
@@ -125,16 +142,15 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
     m_run = m_new;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-    // ---- O^T += V^T . P^T  (A: lane (d, half) holds V[key kt + acc_row(s, half)][d]; B: st[s])
+    // ---- O^T += V^T . P^T  (A: va0/va1; B: st[s])
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int kidx = kt + acc_row(s, half);
-      const bool k_ok = kidx < ke;
-      const float* vp = vbase + (size_t)(k_ok ? kidx : kb) * ldv + qi;
-      const float a0 = k_ok ? vp[0] : 0.f;
-      const float a1 = k_ok ? vp[32] : 0.f;
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st[s], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st[s], o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0[s], st[s], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1[s], st[s], o1, 0, 0, 0);
+    }
+    if (ktn < ke) {
+#pragma unroll
+      for (int s = 0; s < 32; ++s) kcur[s] = knext[s];
     }
   }
 
