@@ -256,10 +256,6 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
 
   int cur = 0;
   int width = ch.in_mode == SIMPB_MLP_IN_SINE2D ? 256 : ch.in_dim;
-  // First weight chunk of the NEXT matrix-core layer, requested while the current layer finishes
-  // (and across the LayerNorm / barrier in between): a layer otherwise starts with a full L2 round trip.
-  float4 pf0[4], pf1[4];
-  int pf_for = -1;
   for (int o = 0; o < ch.n_ops; ++o) {
     const simpb_mlp_op& op = ch.ops[o];
     if (op.type == SIMPB_MLP_LINEAR) {
@@ -275,13 +271,8 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
           const float m0 = cv0 ? 1.f : 0.f, m1 = cv1 ? 1.f : 0.f;
           const float* ar = &act[cur][r16][16 * kq];
           float4 b0[4], b1[4], nb0[4], nb1[4];
-          if (pf_for == o) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { b0[j] = pf0[j]; b1[j] = pf1[j]; }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { b0[j] = *reinterpret_cast<const float4*>(w0 + 4 * j); b1[j] = *reinterpret_cast<const float4*>(w1 + 4 * j); }
-          }
+          for (int j = 0; j < 4; ++j) { b0[j] = *reinterpret_cast<const float4*>(w0 + 4 * j); b1[j] = *reinterpret_cast<const float4*>(w1 + 4 * j); }
           for (int k0 = 0; k0 < K; k0 += 64) {
             const bool more = k0 + 64 < K;
             if (more) {
@@ -316,21 +307,6 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
             const float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
             if (cv0) act[cur ^ 1][4 * kq + r][c0] = op.relu ? fmaxf(v0, 0.f) : v0;
             if (cv1) act[cur ^ 1][4 * kq + r][c1] = op.relu ? fmaxf(v1, 0.f) : v1;
-          }
-        }
-        {  // request chunk 0 of the next matrix-core layer (this wave's columns there)
-          int nx = o + 1;
-          while (nx < ch.n_ops && ch.ops[nx].type != SIMPB_MLP_LINEAR) ++nx;
-          pf_for = -1;
-          if (nx < ch.n_ops && (ch.ops[nx].in_dim & 63) == 0 && wave * 32 < ch.ops[nx].out_dim) {
-            const simpb_mlp_op& nop = ch.ops[nx];
-            const int r16n = lane & 15, kqn = lane >> 4;
-            const int nc0 = wave * 32 + r16n, nc1 = nc0 + 16;
-            const float* nw0 = nop.w + (size_t)(nc0 < nop.out_dim ? nc0 : 0) * nop.in_dim + 16 * kqn;
-            const float* nw1 = nop.w + (size_t)(nc1 < nop.out_dim ? nc1 : 0) * nop.in_dim + 16 * kqn;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { pf0[j] = *reinterpret_cast<const float4*>(nw0 + 4 * j); pf1[j] = *reinterpret_cast<const float4*>(nw1 + 4 * j); }
-            pf_for = nx;
           }
         }
       } else if (tid < D) {  // narrow / odd layers (K = 2, 3, 12, 32; D = 2..11): one thread per column
