@@ -326,3 +326,22 @@ def test_fused_backbone_epilogue_matches_plain_fp16_backbone():
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 2e-2 * scale
     assert float((got - want).abs().mean()) <= 2e-3 * scale
+
+
+def test_mlp_chain_valu_variant_matches_mfma_variant():
+    """The two kernels behind simpb_mlp_chain_forward (matrix-core on weights as stored; VALU on
+    transposed weights) agree."""
+    from simpb_amd.plugin import fused
+    from simpb_amd.plugin.detection3d import SparseBox3DRefinementModule
+    ref3 = SparseBox3DRefinementModule(embed_dims=256, num_cls=10, refine_yaw=True, with_quality_estimation=True).cuda()
+    synth.load_procedural(ref3, seed=7)
+    x = torch.randn(1, 333, 256, device="cuda")
+    e = torch.randn(1, 333, 256, device="cuda")
+    a = fused.chain_forward(ref3.layers, x, e)
+    old = fused.TRANSPOSED_WEIGHTS
+    try:
+        fused.TRANSPOSED_WEIGHTS = True
+        b = fused.chain_forward(ref3.layers, x, e)
+    finally:
+        fused.TRANSPOSED_WEIGHTS = old
+    assert float((a - b).abs().max()) < 2e-5
