@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--meter-frames", type=int, default=8, help="instrumented eager frames for the roofline leg")
     ap.add_argument("--no-conv-search", action="store_true",
                     help="do not let MIOpen benchmark convolution algorithms during warm-up (cudnn.benchmark off)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent camera streams per GPU, each a bs-sized runner of its own replayed concurrently "
+                         "(BASELINE config #3 shape: 8 streams per GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -207,20 +210,34 @@ def main():
     from simpb_amd.dist import gather_detections, pack_detections
     from simpb_amd.runner import FrameRunner, PipelinedRunner
     torch.backends.cudnn.benchmark = not args.no_conv_search
-    model = build_model(args, device)
     total = args.prime + args.warmup + args.steps + args.meter_frames
     imgs = make_frames(args, device, total)
     metas = [frame_metas(args, f) for f in range(total)]  # what a dataloader would hand over
     pipelined = not args.no_pipeline and not args.eager
-    runner = (PipelinedRunner if pipelined else FrameRunner)(
-        model, args.bs, (args.image_wh[1], args.image_wh[0]), capacity=args.capacity, device=device,
-        use_graph=not args.eager)
+    if args.streams > 1 and not pipelined:
+        raise SystemExit("--streams needs the pipelined runner")
+    runners = []
+    for _ in range(args.streams):  # one model replica + runner per independent stream
+        model = build_model(args, device)
+        runners.append((PipelinedRunner if pipelined else FrameRunner)(
+            model, args.bs, (args.image_wh[1], args.image_wh[0]), capacity=args.capacity, device=device,
+            use_graph=not args.eager))
+    runner = runners[0]
     gathered = None
     side = torch.cuda.Stream(device=device)
 
     def step(f, force_eager=False):
         nonlocal gathered
-        results = runner.step(imgs[f % len(imgs)], metas[f], force_eager=force_eager)
+        if len(runners) == 1:
+            results = runner.step(imgs[f % len(imgs)], metas[f], force_eager=force_eager)
+        else:  # launch every stream's frame, then collect: the streams' graphs run side by side
+            for i, r in enumerate(runners):
+                r.launch(imgs[(f + i) % len(imgs)], metas[f], force_eager=force_eager)
+            results = None
+            for r in runners:
+                out = r.collect()
+                if out is not None:
+                    results = (results or []) + out
         if results is None:  # pipelined runner, very first call: nothing decoded yet
             return None
         if dist is not None:  # detections of every stream to every rank, off the compute stream
@@ -267,8 +284,9 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        frames = world * args.bs * args.steps
-        n2 = [int(x) for x in model.head.layers[0].last.count.sum(dim=1).tolist()] if model.head.layers[0].last else None
+        frames = world * args.streams * args.bs * args.steps
+        head0 = runner.head
+        n2 = [int(x) for x in head0.layers[0].last.count.sum(dim=1).tolist()] if head0.layers[0].last else None
         mode = dict(runner.stats, hipgraph=not args.eager, capacity_2d=args.capacity,
                     pipelined_backbone=pipelined)
         def pmc_traffic(kernel):
@@ -300,8 +318,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"simpb_nus_r{args.depth}_img_{args.image_wh[0]}x{args.image_wh[1]}: 6-cam frames, "
-                                   f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, bs={args.bs}/GPU, temporal streams",
-                       "streams_per_gpu": args.bs, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
+                                   f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, {args.streams} stream(s) x bs={args.bs} per GPU, temporal",
+                       "streams_per_gpu": args.bs * args.streams, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
                        if world > 1 else "single GPU", "num_query2d_last_frame": n2, "frame_runner": mode},
             "roofline": roof, "roofline_msda": roof2,
         }

@@ -207,7 +207,7 @@ class PipelinedRunner(FrameRunner):
                     self.head_runs[slot] += 1
             return rec
 
-    def _finish(self, rec, metas):
+    def _enqueue_readback(self, rec):
         with torch.cuda.stream(self.s_head):
             if self.host3d is None:
                 self.host3d = torch.empty(rec[0].shape, dtype=rec[0].dtype).pin_memory()
@@ -216,12 +216,18 @@ class PipelinedRunner(FrameRunner):
             self.host3d.copy_(rec[0], non_blocking=True)
             self.host2d.copy_(rec[1], non_blocking=True)
             self.host_flag.copy_(rec[2], non_blocking=True)
+
+    def _collect(self, metas):
         self.s_head.synchronize()
         if bool(self.host_flag.any()):
             raise RuntimeError(f"2D query set exceeded the static capacity {self.capacity}; use a larger capacity")
         self.prev_metas = dict(img_metas=metas["img_metas"])
         results = SparseBox3DDecoder.decode_static_host(self.host3d.numpy(), self.host2d.numpy(), self.head.num_cams)
         return [{"img_bbox": r} for r in results]
+
+    def _finish(self, rec, metas):
+        self._enqueue_readback(rec)
+        return self._collect(metas)
 
     def _stage_head_inputs(self, metas):
         """Per-frame decoder inputs (projection matrices, ego-motion, time step) of the PENDING frame."""
@@ -237,8 +243,9 @@ class PipelinedRunner(FrameRunner):
                 self.dt_buf.copy_(self.pin_dt, non_blocking=True)
 
     @torch.no_grad()
-    def step(self, img, metas, force_eager=False):
-        """Feed frame t; returns the detections of frame t-1 (None on the very first call)."""
+    def launch(self, img, metas, force_eager=False):
+        """Enqueue backbone(t) and decoder(t-1) without waiting for either (several runners -- several
+        independent camera streams on one GPU -- can be launched back to back and collected after)."""
         slot = self.count % 2
         cur = torch.cuda.current_stream()
         self.s_bb.wait_stream(cur)
@@ -246,17 +253,28 @@ class PipelinedRunner(FrameRunner):
         with torch.cuda.stream(self.s_bb):
             self.imgs[slot].copy_(img, non_blocking=True)
         self._run_backbone(slot, force_eager)
-        results = None
+        self._inflight = None
         if self.pending is not None:
             pslot, pmetas = self.pending
             self._stage_head_inputs(pmetas)
             warm = self.prev_metas is not None
             rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"], warm, force_eager)
-            results = self._finish(rec, pmetas)
+            self._enqueue_readback(rec)
+            self._inflight = pmetas
+        self._next_pending = (slot, metas)
+
+    def collect(self):
+        """Wait for what launch() enqueued; returns the detections of frame t-1 (None the first time)."""
+        results = self._collect(self._inflight) if self._inflight is not None else None
         self.s_bb.synchronize()
-        self.pending = (slot, metas)
+        self.pending = self._next_pending
         self.count += 1
         return results
+
+    def step(self, img, metas, force_eager=False):
+        """Feed frame t; returns the detections of frame t-1 (None on the very first call)."""
+        self.launch(img, metas, force_eager)
+        return self.collect()
 
     @torch.no_grad()
     def flush(self):
