@@ -83,6 +83,9 @@ def test_daf_full_size_properties():
     assert bool((oc <= upper + 1e-3).all())  # border taps only remove mass
     want = R.deformable_aggregation(fm[0], fm[1].int(), fm[2].int(), loc.cpu(), w1.cpu())
     assert float((o1.cpu() - want).abs().max()) <= 1e-4 * max(float(want.abs().max()), 1.0)
+    from oracle import build_c  # the line-by-line C form of the reference kernel, same input
+    want_c = build_c.daf_forward(fm[0].numpy(), fm[1].numpy(), fm[2].numpy(), loc.cpu().numpy(), w1.cpu().numpy())
+    assert float(np.abs(o1.cpu().numpy() - want_c).max()) <= 1e-4 * max(float(np.abs(want_c).max()), 1.0)
 
 
 def _msda_inputs(bs, nq, heads, ch, shapes, pts, ncam, seed):

@@ -117,3 +117,20 @@ def test_head_stream(name):
         assert np.array_equal(outs["instance_id"].numpy(), g[pre + "instance_id#0"])
         for b, r in enumerate(res):
             compare_result(r, g, f"{pre}res{b}.")
+
+
+def test_c_restatement_of_the_native_kernel():
+    """oracle/daf_ref.c (line-by-line C form of the CUDA kernel) against the reference's own PyTorch
+    fallback on interior points and against the PyTorch restatement on border/out-of-range points."""
+    from oracle import build_c
+    g = load_golden("ops.npz")
+    col, ss, ssi, loc, w = daf_case(g)
+    out = build_c.daf_forward(col.numpy(), ss.numpy(), ssi.numpy(), loc.numpy(), w.numpy())
+    assert np.abs(out - g["daf.out_fallback"]).max() < 1e-5
+    rs = np.random.RandomState(4)
+    loc2 = torch.from_numpy(rs.uniform(-0.2, 1.2, loc.shape).astype(np.float32))
+    loc2[0, 0, 0, 0] = torch.tensor([0.0, 0.5])
+    loc2[0, 1, 0, 0] = torch.tensor([0.5, 1.0])
+    want = R.deformable_aggregation(col, ss.int(), ssi.int(), loc2, w)
+    got = build_c.daf_forward(col.numpy(), ss.numpy(), ssi.numpy(), loc2.numpy(), w.numpy())
+    assert np.abs(got - want.numpy()).max() < 1e-5
