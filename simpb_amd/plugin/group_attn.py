@@ -34,7 +34,8 @@ class QueryGroupMultiheadAttention(BaseModule):
         self.dropout_layer = build_dropout(dropout_layer) if dropout_layer else nn.Identity()
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, query_groups=None,
-                group_attn_mask=None, key_padding_mask=None, query_cam=None, group_start=None, **kwargs):
+                group_attn_mask=None, key_padding_mask=None, query_cam=None, group_start=None, value_pre=None,
+                **kwargs):
         if group_attn_mask is not None or key_padding_mask is not None:
             raise NotImplementedError("explicit masks are only used with with_allocate_attn_mask / training")
         same_qk = key is None
@@ -60,9 +61,10 @@ class QueryGroupMultiheadAttention(BaseModule):
             self.query_groups = query_groups
         if query_cam is not None:  # device-side group table (what the allocation kernels emit)
             out = mha_forward(self.attn, query, key, value, same_qk=same_qk, query_cam=query_cam,
-                              group_start=group_start)
+                              group_start=group_start, value_pre=value_pre)
         else:
-            out = mha_forward(self.attn, query, key, value, groups=self.query_groups, same_qk=same_qk)
+            out = mha_forward(self.attn, query, key, value, groups=self.query_groups, same_qk=same_qk,
+                              value_pre=value_pre)
         if not self.batch_first:
             out = out.transpose(0, 1)
         return identity + self.dropout_layer(self.proj_drop(out))

@@ -161,10 +161,12 @@ class SimPBHead(BaseModule):
         """simpb_head.py:298-310."""
         query = torch.cat([query, query_pos], dim=-1)
         key = torch.cat([key, key_pos], dim=-1) if key is not None else None
-        value = self.fc_before(value) if value is not None else None
         layer = self.layers[index] if isinstance(index, int) else index
         kwargs.pop("attn_mask", None)
-        return self.fc_after(layer(query, key, value, query_pos=None, key_pos=None, **kwargs))
+        # fc_before (:303) is handed to the attention operator, which applies it on the value branch,
+        # forked from the q/k projection branch (layers.run_parallel)
+        pre = self.fc_before if value is not None else None
+        return self.fc_after(layer(query, key, value, query_pos=None, key_pos=None, value_pre=pre, **kwargs))
 
     def graph_model2d(self, index, query, key=None, value=None, query_pos=None, key_pos=None, **kwargs):
         """simpb_head.py:312-321."""
@@ -172,8 +174,9 @@ class SimPBHead(BaseModule):
             query = torch.cat([query, query_pos], dim=-1)
             key = torch.cat([key, key_pos], dim=-1) if key is not None else None
             query_pos, key_pos = None, None
-        value = self.fc_before2d(value) if value is not None else None
-        return self.fc_after2d(self.layers[index](query, key, value, query_pos=query_pos, key_pos=key_pos, **kwargs))
+        pre = self.fc_before2d if value is not None and isinstance(self.fc_before2d, nn.Linear) else None
+        return self.fc_after2d(self.layers[index](query, key, value, query_pos=query_pos, key_pos=key_pos,
+                                                  value_pre=pre, **kwargs))
 
     # ------------------------------------------------------------------ forward
     def forward(self, feature_maps, metas: dict):

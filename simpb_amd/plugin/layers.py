@@ -75,7 +75,34 @@ def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
     return layers
 
 
-def mha_forward(attn, query, key, value, groups=None, same_qk=False, query_cam=None, group_start=None):
+PARALLEL_BRANCHES = True
+_side_streams = {}
+
+
+def run_parallel(fn_a, fn_b, device):
+    """(fn_a(), fn_b()) with fn_b enqueued on a side HIP stream: two independent small GEMM chains
+    (e.g. the q/k projection and the value path of an attention operator) each occupy well under
+    half of the 256 CUs, so they are forked and joined instead of serialised. Works the same inside
+    a graph capture (the fork/join becomes graph edges) and in eager mode."""
+    if not PARALLEL_BRANCHES or device.type != "cuda":
+        return fn_a(), fn_b()
+    cur = torch.cuda.current_stream(device)
+    key = (device.index, cur.cuda_stream)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        b = fn_b()
+    a = fn_a()
+    cur.wait_stream(side)
+    for t in (b if isinstance(b, (tuple, list)) else (b,)):
+        if torch.is_tensor(t):
+            t.record_stream(cur)
+    return a, b
+
+
+def mha_forward(attn, query, key, value, groups=None, same_qk=False, query_cam=None, group_start=None, value_pre=None):
     """Arithmetic of torch.nn.MultiheadAttention.forward for batch-first [bs, N, E] inputs, using
     `attn` (an nn.MultiheadAttention) purely as the parameter container so checkpoint keys stay
     `attn.in_proj_weight/in_proj_bias/out_proj.*`.
@@ -90,13 +117,16 @@ def mha_forward(attn, query, key, value, groups=None, same_qk=False, query_cam=N
     hd = e // h
     w, b = attn.in_proj_weight, attn.in_proj_bias
     bs, nq, _ = query.shape
-    if same_qk:
-        qk = F.linear(query, w[: 2 * e], b[: 2 * e])
-        q, k = qk[..., :e], qk[..., e:]
-    else:
-        q = F.linear(query, w[:e], b[:e])
-        k = F.linear(key, w[e: 2 * e], b[e: 2 * e])
-    v = F.linear(value, w[2 * e:], b[2 * e:])
+    def qk_path():
+        if same_qk:
+            qk = F.linear(query, w[: 2 * e], b[: 2 * e])
+            return qk[..., :e], qk[..., e:]
+        return F.linear(query, w[:e], b[:e]), F.linear(key, w[e: 2 * e], b[e: 2 * e])
+
+    def v_path():  # value_pre: a projection applied to the raw value first (fc_before, simpb_head.py:303)
+        return F.linear(value_pre(value) if value_pre is not None else value, w[2 * e:], b[2 * e:])
+
+    (q, k), v = run_parallel(qk_path, v_path, query.device)
     if q.is_cuda and hd == 64:
         from .ops import attention_f32
         if query_cam is not None and group_start is None:
@@ -141,7 +171,7 @@ class MultiheadAttention(BaseModule):
         self.dropout_layer = build_dropout(dropout_layer) if dropout_layer else nn.Identity()
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
-                key_padding_mask=None, **kwargs):
+                key_padding_mask=None, value_pre=None, **kwargs):
         if attn_mask is not None or key_padding_mask is not None:
             raise NotImplementedError("attention masks only occur on the reference's training path")
         same_qk = key is None
@@ -163,7 +193,7 @@ class MultiheadAttention(BaseModule):
                 key = key + key_pos
         if not self.batch_first:
             query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
-        out = mha_forward(self.attn, query, key, value, same_qk=same_qk)
+        out = mha_forward(self.attn, query, key, value, same_qk=same_qk, value_pre=value_pre)
         if not self.batch_first:
             out = out.transpose(0, 1)
         return identity + self.dropout_layer(self.proj_drop(out))
