@@ -75,7 +75,10 @@ def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
     return layers
 
 
-PARALLEL_BRANCHES = True
+# Measured on MI355X (round 1): forking the value branch of each attention operator onto a side stream
+# LOSES time inside the replayed frame graph (179-188 -> 163 frames/s): a cross-stream edge in a
+# hipGraph costs more than two ~12 us GEMMs gain by overlapping. Kept for experiments, off by default.
+PARALLEL_BRANCHES = False
 _side_streams = {}
 
 
