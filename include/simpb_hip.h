@@ -101,6 +101,45 @@ int simpb_ms_deform_attn_grouped_backward(
 int simpb_linear_f32(float* y, const float* x, const float* weight, const float* bias, int M, int N, int K,
                      int relu, void* stream);
 
+/* Grouped small GEMM of the decoder: up to 4 independent problems per launch, each
+ *   y[M, 0:N] (row stride ldy) = relu?( [x0 | x1 | ...][M, K] . w[N, K]^T (row stride ldw) + bias[N] )
+ * where x is given as up to 4 column segments (pointer, row stride, width; widths sum to K). This is
+ * how the reference's `torch.cat([feature, pos_embed], -1)` in front of every attention projection
+ * (models/simpb_head.py:298-321), the `identity + out` branches followed by fc_after (:306-310) and
+ * the identity_fc branch of AsymmetricFFN (models/blocks.py:384-393) become one product each, with
+ * host-folded weights, instead of a concatenation, two vendor GEMMs and an add. Exact fp32
+ * (v_mfma_f32_32x32x2_f32). Every segment width and K are multiples of 64; x, w 16-byte aligned,
+ * row strides multiples of 4. m_live (device int, may be NULL): rows >= *m_live are capacity slots of the
+ * static 2D query set and are written as zeros. Deterministic. */
+#define SIMPB_GEMM_MAX_SEGS 4
+#define SIMPB_GEMM_MAX_JOBS 4
+typedef struct simpb_gemm_job {
+  const float* x[SIMPB_GEMM_MAX_SEGS];
+  int ldx[SIMPB_GEMM_MAX_SEGS];
+  int kseg[SIMPB_GEMM_MAX_SEGS];
+  int num_seg;
+  int M, N, K;
+  const float* w;
+  const float* bias;
+  float* y;
+  const int* m_live;
+  int ldw, ldy, relu, reserved;
+} simpb_gemm_job;
+typedef struct simpb_gemm_args {
+  int num_jobs;
+  int reserved;
+  simpb_gemm_job job[SIMPB_GEMM_MAX_JOBS];
+} simpb_gemm_args;
+int simpb_gemm_f32(const simpb_gemm_args* args, void* stream);
+
+/* out[M, 0:k0+k1] (row stride ldo) = LayerNorm([x0 | x1]) * gamma + beta over the concatenated width
+ * (torch.nn.LayerNorm: eps 1e-5, biased variance); x1 may be NULL with k1 = 0. Width <= 512. The two
+ * segments are the `cat` of residual_mode="cat" (models/blocks.py:158-161, group_attn.py:252-255) in front
+ * of the FFN's pre_norm (blocks.py:385-386), and one segment is every `norm` op of the decoder.
+ * m_live as in simpb_gemm_f32. out may alias x0 when k1 == 0. */
+int simpb_layernorm_f32(float* out, int ldo, const float* x0, int ld0, int k0, const float* x1, int ld1, int k1,
+                        const float* gamma, const float* beta, int num_rows, const int* m_live, void* stream);
+
 /* Forward direction of feature_maps_format (ops/__init__.py:63-92) in one pass. Level l is
  * [num_images = bs*cams, H_l, W_l, channels] in memory (what a channels_last backbone emits), f16
  * (src_is_half) or f32; level_ptrs/level_hw are HOST arrays of num_levels device pointers / H_l*W_l.

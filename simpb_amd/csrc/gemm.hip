@@ -1,0 +1,280 @@
+// Grouped small-GEMM kernel of the decoder (gfx950, exact fp32 on v_mfma_f32_32x32x2_f32) and the
+// segmented LayerNorm that goes with it.
+//
+// What it replaces: every `nn.Linear` of the decoder whose M is the query count (900 anchors, 600
+// cached instances, <= 1 536 2D slots) -- the in/out projections of the four attention operators
+// (/root/reference/projects/mmdet3d_plugin/models/simpb_head.py:298-321, group_attn.py:60-133), the
+// AsymmetricFFN (blocks.py:384-393), output_proj / weights_fc / learnable_fc of the deformable
+// operators (blocks.py:110-196, group_attn.py:176-243) -- together with the `torch.cat` / `+` that
+// feed them. In the reference each is one vendor GEMM of 0.1-0.9 GFLOP (8-15 us on MI355X through
+// the vendor heuristic, 3-5 % of the fp32 matrix rate) plus 1-3 elementwise kernels.
+//
+// Shape of the problem: M ~ 1 k, N and K in 256..1 536. A 64x256 tile (csrc/linear.hip, built for
+// the 90 k-row value projection) would give 15-60 workgroups on a 256-CU chip, so the tile here is
+// 32 x 32 (or 32 x 64) and the FOUR WAVES OF A WORKGROUP SPLIT K: each wave owns the whole output
+// tile over a quarter (half) of every 64-wide K chunk, so no operand is read from LDS twice, and the
+// partial tiles meet once in LDS at the end. M = 900, N = 256 is 232 workgroups.
+//
+//  * X is given as up to four COLUMN SEGMENTS (pointer, row stride, width): y = [x0 | x1 | ...] W^T.
+//    That is how cat([feature, pos_embed]) (simpb_head.py:299-301), the `identity +` branches and the
+//    FFN's identity_fc are folded into one product without materialising the concatenation.
+//  * Up to four independent problems share a launch (q / kv projections of the temporal attention).
+//  * `m_live` (device int, optional): rows >= *m_live are capacity slots of the static 2D query set;
+//    they are written as zeros without touching X or W.
+//  * Two K chunks are kept in flight in registers ahead of the one being multiplied; LDS is double
+//    buffered, one barrier per chunk.
+//  * Workgroups are numbered so that each XCD (blockIdx % 8) walks a contiguous range of tiles:
+//    neighbouring tiles share their X rows in that XCD's L2.
+#include <hip/hip_runtime.h>
+#include "../../include/simpb_hip.h"
+
+extern "C" int simpb_check_launch(void);
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 32, BK = 64, LDK = BK + 4;
+constexpr int kThreads = 256;
+
+struct GemmLaunch {
+  simpb_gemm_args a;
+  int tile_start[SIMPB_GEMM_MAX_JOBS + 1];
+  int per_xcd;  // tiles per XCD range
+};
+
+template <int BN>
+__global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
+  constexpr int WN = BN / 32;         // waves across N
+  constexpr int WK = 4 / WN;          // waves across K
+  constexpr int KW = BK / WK;         // k values of a chunk per wave
+  constexpr int KH = KW / 2;          // ... per lane half
+  constexpr int NW4 = BN / 16;        // float4 W loads per thread per chunk
+  constexpr int LDP = BN + 1;
+  constexpr int kStage = 2 * (BM + BN) * LDK;
+  constexpr int kPart = WK * BM * LDP;
+  __shared__ float smem[kStage > kPart ? kStage : kPart];
+  float* s_x = smem;                     // [2][BM][LDK]
+  float* s_w = smem + 2 * BM * LDK;      // [2][BN][LDK]
+
+  // ---- which tile
+  const int total = L.tile_start[L.a.num_jobs];
+  const int tile = (blockIdx.x & 7) * L.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= L.per_xcd || tile >= total) return;
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < SIMPB_GEMM_MAX_JOBS; ++t)
+    if (t < L.a.num_jobs && tile >= L.tile_start[t]) j = t;
+  const simpb_gemm_job& job = L.a.job[j];
+  const int local = tile - L.tile_start[j];
+  const int tiles_n = (job.N + BN - 1) / BN;
+  const int row0 = (local / tiles_n) * BM;
+  const int col0 = (local % tiles_n) * BN;
+  const int M = job.M, N = job.N, K = job.K;
+  const int live = job.m_live ? min(M, *job.m_live) : M;
+
+  const int tid = threadIdx.x;
+  float* __restrict__ y = job.y;
+  if (row0 >= live) {  // capacity rows: zeros
+    for (int idx = tid; idx < BM * BN; idx += kThreads) {
+      const int r = idx / BN, c = idx - r * BN;
+      if (row0 + r < M && col0 + c < N) y[(size_t)(row0 + r) * job.ldy + col0 + c] = 0.f;
+    }
+    return;
+  }
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int wn = wave % WN, wk = wave / WN;
+
+  // ---- staging: thread f -> (row f >> 4, float4 column f & 15) of a [rows][64] chunk
+  const int sr = tid >> 4, sc4 = tid & 15;
+  float4 px[2][2], pw[2][NW4];
+  const float* __restrict__ w = job.w;
+
+  // segment walk state per register set is recomputed from the chunk index (<= 4 segments)
+  auto fetch = [&](int set, int k0) {
+    int seg = 0, koff = k0;
+#pragma unroll
+    for (int s = 0; s < SIMPB_GEMM_MAX_SEGS - 1; ++s)
+      if (seg == s && s + 1 < job.num_seg && koff >= job.kseg[s]) { koff -= job.kseg[s]; seg = s + 1; }
+    const float* __restrict__ xs = job.x[seg];
+    const int ldx = job.ldx[seg];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gr = row0 + sr + 16 * i;
+      px[set][i] = gr < live ? *reinterpret_cast<const float4*>(xs + (size_t)gr * ldx + koff + sc4 * 4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+      const int gc = col0 + sr + 16 * i;
+      pw[set][i] = gc < N ? *reinterpret_cast<const float4*>(w + (size_t)gc * job.ldw + k0 + sc4 * 4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&](int set, int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<float4*>(&s_x[(buf * BM + sr + 16 * i) * LDK + sc4 * 4]) = px[set][i];
+#pragma unroll
+    for (int i = 0; i < NW4; ++i)
+      *reinterpret_cast<float4*>(&s_w[(buf * BN + sr + 16 * i) * LDK + sc4 * 4]) = pw[set][i];
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  auto multiply = [&](int buf) {
+    // lane (r32, half) holds k = wk*KW + half*KH + 0..KH-1 of its x row and of its W row: the same
+    // permutation of k on both operands, so the product is unchanged and both arrive as b128 reads
+    const float* ax = &s_x[(buf * BM + r32) * LDK + wk * KW + half * KH];
+    const float* bx = &s_w[(buf * BN + wn * 32 + r32) * LDK + wk * KW + half * KH];
+    float a[KH], b[KH];
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+      const float4 va = *reinterpret_cast<const float4*>(ax + 4 * q);
+      const float4 vb = *reinterpret_cast<const float4*>(bx + 4 * q);
+      a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
+      b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
+    }
+#pragma unroll
+    for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  };
+
+  const int nchunks = K / BK;
+  fetch(0, 0);
+  if (nchunks > 1) fetch(1, BK);
+  for (int c = 0; c < nchunks; c += 2) {
+    stash(0, 0);
+    __syncthreads();
+    if (c + 2 < nchunks) fetch(0, (c + 2) * BK);
+    multiply(0);
+    if (c + 1 < nchunks) {
+      stash(1, 1);
+      __syncthreads();
+      if (c + 3 < nchunks) fetch(1, (c + 3) * BK);
+      multiply(1);
+    }
+  }
+
+  // ---- the WK partial tiles meet in LDS (C/D layout of the 32x32 tile: column = lane & 31,
+  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+  __syncthreads();
+  float* part = smem;  // [WK][BM][LDP]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    part[(wk * BM + row) * LDP + wn * 32 + r32] = acc[r];
+  }
+  __syncthreads();
+  const float* __restrict__ bias = job.bias;
+  for (int idx = tid; idx < BM * BN; idx += kThreads) {
+    const int r = idx / BN, c = idx - r * BN;
+    const int gr = row0 + r, gc = col0 + c;
+    if (gr < M && gc < N) {
+      float v = part[r * LDP + c];
+#pragma unroll
+      for (int p = 1; p < WK; ++p) v += part[(p * BM + r) * LDP + c];  // fixed order: deterministic
+      if (bias) v += bias[gc];
+      if (job.relu) v = fmaxf(v, 0.f);
+      y[(size_t)gr * job.ldy + gc] = gr < live ? v : 0.f;
+    }
+  }
+}
+
+// ---- LayerNorm over the concatenation of up to two column segments, one wave per row, eps 1e-5,
+// biased variance (torch.nn.LayerNorm); width <= 512, multiple of 64 per segment.
+__global__ __launch_bounds__(256) void layernorm_seg_kernel(float* __restrict__ out, int ldo,
+                                                            const float* __restrict__ x0, int ld0, int k0,
+                                                            const float* __restrict__ x1, int ld1, int k1,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int M,
+                                                            const int* __restrict__ m_live) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int D = k0 + k1;
+  const int live = m_live ? min(M, *m_live) : M;
+  float v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const int e = lane + 64 * jj;
+    float t = 0.f;
+    if (e < D && row < live) t = e < k0 ? x0[(size_t)row * ld0 + e] : x1[(size_t)row * ld1 + (e - k0)];
+    v[jj] = t;
+    s += t;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const float d = (lane + 64 * jj) < D ? v[jj] - mean : 0.f;
+    q += d * d;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+  const float inv = 1.f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const int e = lane + 64 * jj;
+    if (e < D) out[(size_t)row * ldo + e] = row < live ? (v[jj] - mean) * inv * gamma[e] + beta[e] : 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
+  if (!args || args->num_jobs <= 0 || args->num_jobs > SIMPB_GEMM_MAX_JOBS) return SIMPB_EINVAL;
+  GemmLaunch L;
+  L.a = *args;
+  // tile width: 64 columns once that still fills the chip, 32 otherwise
+  long long tiles64 = 0;
+  for (int j = 0; j < args->num_jobs; ++j) {
+    const simpb_gemm_job& job = args->job[j];
+    if (!job.y || !job.w || job.M <= 0 || job.N <= 0 || job.K <= 0 || job.K % BK) return SIMPB_EINVAL;
+    if (job.num_seg <= 0 || job.num_seg > SIMPB_GEMM_MAX_SEGS || job.ldy < job.N || job.ldw < job.K) return SIMPB_EINVAL;
+    if ((reinterpret_cast<size_t>(job.w) & 15) || (job.ldw & 3)) return SIMPB_EINVAL;
+    int ksum = 0;
+    for (int s = 0; s < job.num_seg; ++s) {
+      if (!job.x[s] || job.kseg[s] <= 0 || job.kseg[s] % BK || job.ldx[s] < job.kseg[s] || (job.ldx[s] & 3) ||
+          (reinterpret_cast<size_t>(job.x[s]) & 15))
+        return SIMPB_EINVAL;
+      ksum += job.kseg[s];
+    }
+    if (ksum != job.K) return SIMPB_EINVAL;
+    tiles64 += (long long)((job.M + BM - 1) / BM) * ((job.N + 63) / 64);
+  }
+  const int bn = tiles64 >= 200 ? 64 : 32;
+  long long total = 0;
+  for (int j = 0; j < args->num_jobs; ++j) {
+    L.tile_start[j] = (int)total;
+    total += (long long)((args->job[j].M + BM - 1) / BM) * ((args->job[j].N + bn - 1) / bn);
+  }
+  if (total > (1 << 24)) return SIMPB_EINVAL;
+  for (int j = args->num_jobs; j <= SIMPB_GEMM_MAX_JOBS; ++j) L.tile_start[j] = (int)total;
+  L.per_xcd = (int)((total + 7) / 8);
+  (void)hipGetLastError();
+  dim3 grid(L.per_xcd * 8);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (bn == 64)
+    hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(kThreads), 0, s, L);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel<32>, grid, dim3(kThreads), 0, s, L);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_layernorm_f32(float* out, int ldo, const float* x0, int ld0, int k0, const float* x1, int ld1,
+                                   int k1, const float* gamma, const float* beta, int num_rows, const int* m_live,
+                                   void* stream) {
+  if (!out || !x0 || !gamma || !beta || num_rows <= 0 || k0 <= 0 || k1 < 0 || (k1 > 0 && !x1)) return SIMPB_EINVAL;
+  if (k0 + k1 > 512 || ldo < k0 + k1 || ld0 < k0 || (k1 > 0 && ld1 < k1)) return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(layernorm_seg_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     out, ldo, x0, ld0, k0, x1, ld1, k1, gamma, beta, num_rows, m_live);
+  return simpb_check_launch();
+}

@@ -3,6 +3,7 @@ DenseDepthNet, which is an auxiliary training loss only: simpb.py:83-86,104-107)
 import torch
 import torch.nn as nn
 
+from . import dense
 from .layers import (BaseModule, Linear, Sequential, build_activation_layer, build_dropout, build_norm_layer,
                      linear_relu_ln)
 from .ops import deformable_aggregation_function as DAF
@@ -56,10 +57,10 @@ class DeformableFeatureAggregation(BaseModule):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.constant_(self.output_proj.bias, 0.0)
 
-    def forward(self, instance_feature, anchor, anchor_embed, feature_maps, metas, **kwargs):
+    def forward(self, instance_feature, anchor, anchor_embed, feature_maps, metas, keep_parts=False, **kwargs):
         if (instance_feature.is_cuda and self.camera_encoder is not None and metas.get("image_wh") is not None
                 and getattr(self.kps_generator, "num_learnable_pts", 0) > 0):
-            return self._forward_fused(instance_feature, anchor, anchor_embed, feature_maps, metas)
+            return self._forward_fused(instance_feature, anchor, anchor_embed, feature_maps, metas, keep_parts)
         bs, num_anchor = instance_feature.shape[:2]
         key_points = self.kps_generator(anchor, instance_feature)
         weights = self._get_weights(instance_feature, anchor_embed, metas)
@@ -78,12 +79,14 @@ class DeformableFeatureAggregation(BaseModule):
             output = torch.cat([output, instance_feature], dim=-1)
         return output
 
-    def _forward_fused(self, instance_feature, anchor, anchor_embed, feature_maps, metas):
+    def _forward_fused(self, instance_feature, anchor, anchor_embed, feature_maps, metas, keep_parts=False):
         """Same dataflow as forward(), with the operand producers as two HIP kernels writing the
-        aggregation kernel's own layouts (csrc/dfa_prep.hip) instead of ~25 PyTorch kernels."""
+        aggregation kernel's own layouts (csrc/dfa_prep.hip) instead of ~25 PyTorch kernels, and the
+        three Linear layers in front of them (learnable_fc on the feature, weights_fc on feature +
+        anchor_embed and on the camera embedding) as one grouped GEMM launch."""
         from .. import _lib
         from . import fused
-        from .ops import _ptr, _stream, linear_f32
+        from .ops import _ptr, _stream
         lib = _lib.lib()
         bs, num_anchor = instance_feature.shape[:2]
         kps = self.kps_generator
@@ -91,26 +94,38 @@ class DeformableFeatureAggregation(BaseModule):
         anchor_c = anchor.contiguous().float()
         proj = metas["projection_mat"].contiguous().float()
         wh = metas["image_wh"].contiguous().float()
-        learn = kps.learnable_fc(instance_feature).contiguous()
+        cam_embed = fused.chain_forward(self.camera_encoder, proj[:, :, :3].reshape(bs, self.num_cams, -1))
+        # weights_fc(f + e) = [f | e] . [W | W]^T + b; weights_fc(f + e + c) = that + c . W^T (no second bias)
+        if dense.ENABLED:
+            learn, feat_logits, cam_logits = dense.gemm(
+                dense.job(instance_feature, kps.learnable_fc.weight, kps.learnable_fc.bias),
+                dense.job([instance_feature, anchor_embed], dense.fold_sum_input(self.weights_fc), self.weights_fc.bias),
+                dense.job(cam_embed, self.weights_fc.weight))
+        else:
+            from .ops import linear_f32
+            learn = kps.learnable_fc(instance_feature).contiguous()
+            feat_logits = linear_f32(instance_feature + anchor_embed, self.weights_fc.weight, self.weights_fc.bias)
+            cam_logits = linear_f32(cam_embed, self.weights_fc.weight)
         num_fix = kps.fix_scale.shape[0]
         loc = torch.empty(bs, num_anchor, self.num_pts, self.num_cams, 2, device=dev)
         _lib.check(lib.simpb_dfa_points(_ptr(loc), None, _ptr(anchor_c), _ptr(learn), _ptr(kps.fix_scale), _ptr(proj),
                                         _ptr(wh), bs, num_anchor, num_fix, kps.num_learnable_pts, self.num_cams,
                                         _stream()), "simpb_dfa_points")
-        feature = instance_feature + anchor_embed
-        cam_embed = fused.chain_forward(self.camera_encoder, proj[:, :, :3].reshape(bs, self.num_cams, -1))
-        feat_logits = linear_f32(feature, self.weights_fc.weight, self.weights_fc.bias)
-        cam_logits = linear_f32(cam_embed, self.weights_fc.weight)
         weights = torch.empty(bs, num_anchor, self.num_pts, self.num_cams, self.num_levels, self.num_groups, device=dev)
         _lib.check(lib.simpb_dfa_weights(_ptr(weights), _ptr(feat_logits), _ptr(cam_logits), bs, num_anchor,
                                          self.num_cams, self.num_levels, self.num_pts, self.num_groups, _stream()),
                    "simpb_dfa_weights")
         features = DAF(*feature_maps, loc, weights).reshape(bs, num_anchor, self.embed_dims)
-        output = self.proj_drop(self.output_proj(features))
+        if dense.ENABLED:
+            output = dense.linear(features, self.output_proj.weight, self.output_proj.bias)
+        else:
+            output = self.output_proj(features)
         if self.residual_mode == "add":
             output = output + instance_feature
         elif self.residual_mode == "cat":
-            output = torch.cat([output, instance_feature], dim=-1)
+            output = dense.Segments([output, instance_feature])
+            if not keep_parts:
+                output = output.materialize()
         return output
 
     def _get_weights(self, instance_feature, anchor_embed, metas=None):
@@ -205,7 +220,23 @@ class AsymmetricFFN(BaseModule):
         if self.add_identity:
             self.identity_fc = nn.Identity() if in_channels == embed_dims else Linear(self.in_channels, embed_dims)
 
-    def forward(self, x, identity=None):
+    def _fusable(self):
+        return (isinstance(self.pre_norm, nn.LayerNorm) and self.num_fcs == 2 and self.add_identity
+                and isinstance(self.identity_fc, nn.Linear) and isinstance(self.activate, nn.ReLU)
+                and isinstance(self.dropout_layer, (nn.Identity, nn.Dropout)))
+
+    def forward(self, x, identity=None, m_live=None):
+        first = x[0] if isinstance(x, dense.Segments) else x
+        if dense.ENABLED and first.is_cuda and identity is None and not self.training and self._fusable():
+            # blocks.py:384-393 in three launches: pre-norm over the (possibly two-segment) input,
+            # fc1 + ReLU, then [h | x] . [W_2 | W_id]^T + b_2 + b_id (dense.fold_ffn_out)
+            xn = dense.layernorm(x, self.pre_norm, m_live=m_live)
+            fc1, fc2 = self.layers[0][0], self.layers[1]
+            h = dense.linear(xn, fc1.weight, fc1.bias, relu=True, m_live=m_live)
+            w, b = dense.fold_ffn_out(fc2, self.identity_fc)
+            return dense.linear([h, xn], w, b, m_live=m_live)
+        if isinstance(x, dense.Segments):
+            x = x.materialize()
         if self.pre_norm is not None:
             x = self.pre_norm(x)
         out = self.layers(x)

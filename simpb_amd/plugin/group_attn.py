@@ -5,6 +5,7 @@ import warnings
 import torch
 import torch.nn as nn
 
+from . import dense
 from .layers import BaseModule, build_dropout, mha_forward
 from .ops import linear_f32, ms_deform_attn_grouped, query_cam_from_groups
 from .registry import ATTENTION
@@ -106,12 +107,15 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, level_start_index=None, query_cam=None,
-                value_is_projected=False, **kwargs):
+                value_is_projected=False, m_live=None, keep_parts=False, **kwargs):
         if value is None:
             value = query
         if identity is None:
             identity = query
-        if query_pos is not None:
+        fused = (dense.ENABLED and query.is_cuda and query_pos is not None and self.batch_first
+                 and query.shape == query_pos.shape)
+        raw_query = query
+        if query_pos is not None and not fused:
             query = query + query_pos
         if not self.batch_first:
             query = query.permute(1, 0, 2)
@@ -124,9 +128,16 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
             assert bcs // self.num_cams == bs
             value = self.project_value(value, key_padding_mask)
         value = value.reshape(bs, self.num_cams, num_value, self.num_heads, -1)
-        sampling_offsets = self.sampling_offsets(query).view(
-            bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
-        attention_weights = self.attention_weights(query).view(
+        if fused:
+            # sampling_offsets(q + pos) and attention_weights(q + pos) as one product [q | pos] . [W | W]^T
+            w, b = dense.fold_stack("msda_in", [self.sampling_offsets, self.attention_weights], copies=2)
+            both = dense.linear([raw_query, query_pos], w, b, m_live=m_live)
+            n_off = self.sampling_offsets.out_features
+            sampling_offsets, attention_weights = both[..., :n_off], both[..., n_off:]
+        else:
+            sampling_offsets, attention_weights = self.sampling_offsets(query), self.attention_weights(query)
+        sampling_offsets = sampling_offsets.reshape(bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+        attention_weights = attention_weights.reshape(
             bs, num_query, self.num_heads, self.num_levels * self.num_points).softmax(-1)
         attention_weights = attention_weights.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
         if reference_points.shape[-1] not in (2, 3):
@@ -142,12 +153,17 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
             query_cam = query_cam_from_groups(self.query_groups, num_query, query.device)
         output = ms_deform_attn_grouped(value, spatial_shapes, level_start_index, sampling_locations,
                                         attention_weights, query_cam)
-        output = self.output_proj(output)
+        if fused:
+            output = dense.linear(output, self.output_proj.weight, self.output_proj.bias, m_live=m_live)
+        else:
+            output = self.output_proj(output)
         if not self.batch_first:
             output = output.permute(1, 0, 2)
         output = self.dropout(output)
         if self.residual_mode == "add":
             output = output + identity
         elif self.residual_mode == "cat":
-            output = torch.cat([output, identity], dim=-1)
+            output = dense.Segments([output, identity])
+            if not keep_parts:
+                output = output.materialize()
         return output

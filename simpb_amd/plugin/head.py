@@ -11,7 +11,8 @@ from . import training_stubs  # noqa: F401  (registers the inert training-only c
 from .allocation import gather_rows
 from .registry import (ATTENTION, BBOX_CODERS, BBOX_SAMPLERS, FEEDFORWARD_NETWORK, HEADS, LOSSES, NORM_LAYERS,
                        PLUGIN_LAYERS, POSITIONAL_ENCODING, TRANSFORMER_LAYER_SEQUENCE, build_from_cfg)
-from .layers import BaseModule
+from . import dense
+from .layers import BaseModule, fused_graph_attention
 
 __all__ = ["SimPBHead"]
 
@@ -104,6 +105,7 @@ class SimPBHead(BaseModule):
             self.fc_after2d = nn.Identity()
         self.use_deformable_func = True  # set by SimPB.__init__ in the reference (simpb.py:53)
         self._tables = None
+        self._m_live = None  # device int: live 2D slots of the static slot array (dense.py), 2D state only
         # None: size the 2D query set exactly each frame (one count readback, the reference's
         # behaviour). An int: static shapes with that many 2D slots and no host round trip inside
         # the frame, which is what lets simpb_amd.runner replay the frame as one hipGraph.
@@ -159,10 +161,14 @@ class SimPBHead(BaseModule):
     # ------------------------------------------------------------------ decoupled attention
     def graph_model(self, index, query, key=None, value=None, query_pos=None, key_pos=None, **kwargs):
         """simpb_head.py:298-310."""
-        query = torch.cat([query, query_pos], dim=-1)
-        key = torch.cat([key, key_pos], dim=-1) if key is not None else None
         layer = self.layers[index] if isinstance(index, int) else index
         kwargs.pop("attn_mask", None)
+        if query.is_cuda and dense.ENABLED:
+            out = fused_graph_attention(layer, self.fc_before, self.fc_after, query, query_pos, key, key_pos, value)
+            if out is not None:
+                return out
+        query = torch.cat([query, query_pos], dim=-1)
+        key = torch.cat([key, key_pos], dim=-1) if key is not None else None
         # fc_before (:303) is handed to the attention operator, which applies it on the value branch,
         # forked from the q/k projection branch (layers.run_parallel)
         pre = self.fc_before if value is not None else None
@@ -170,6 +176,12 @@ class SimPBHead(BaseModule):
 
     def graph_model2d(self, index, query, key=None, value=None, query_pos=None, key_pos=None, **kwargs):
         """simpb_head.py:312-321."""
+        if self.decouple_attn2d and query.is_cuda and dense.ENABLED and kwargs.get("query_cam") is not None:
+            out = fused_graph_attention(self.layers[index], self.fc_before2d, self.fc_after2d, query, query_pos, key,
+                                        key_pos, value, query_cam=kwargs["query_cam"],
+                                        group_start=kwargs.get("group_start"), m_live=self._m_live)
+            if out is not None:
+                return out
         if self.decouple_attn2d:
             query = torch.cat([query, query_pos], dim=-1)
             key = torch.cat([key, key_pos], dim=-1) if key is not None else None
@@ -177,6 +189,11 @@ class SimPBHead(BaseModule):
         pre = self.fc_before2d if value is not None and isinstance(self.fc_before2d, nn.Linear) else None
         return self.fc_after2d(self.layers[index](query, key, value, query_pos=query_pos, key_pos=key_pos,
                                                   value_pre=pre, **kwargs))
+
+    def _next_is_ffn(self, i):
+        """True when op i+1 is the FFN, whose pre-norm reads a residual_mode="cat" result as two
+        segments in place (dense.Segments) instead of a materialised concatenation."""
+        return i + 1 < len(self.operation_order) and self.operation_order[i + 1] == "ffn"
 
     # ------------------------------------------------------------------ forward
     def forward(self, feature_maps, metas: dict):
@@ -202,19 +219,27 @@ class SimPBHead(BaseModule):
         pre_values = feature_maps[3] if len(feature_maps) > 3 else None
         encoder2d_dict, feature_maps = self.prepare2d(feature_maps, metas)
         alloc = None
+        self._m_live = None
         last = len(self.operation_order) - 1
 
         for i, op in enumerate(self.operation_order):
             layer = self.layers[i]
             if layer is None:
                 continue
-            elif op == "norm" or op == "ffn":
-                instance_feature = layer(instance_feature)
+            elif op == "norm":
+                if instance_feature.is_cuda and dense.ENABLED:
+                    instance_feature = dense.layernorm(instance_feature, layer, m_live=self._m_live)
+                else:
+                    instance_feature = layer(instance_feature)
+            elif op == "ffn":
+                instance_feature = layer(instance_feature, m_live=self._m_live)
             elif op == "allocation":
                 assert self.instance_status == "3d"
                 anchor2d, ref_depth2d, ref_trans_mask, ref_trans_shape, _, _, ref_query_groups, _ = layer(
                     anchor, metas, dense=False, capacity=cap)
                 alloc = layer.last
+                if cap is not None and batch_size == 1 and alloc.group_start is not None:
+                    self._m_live = alloc.group_start[self.num_cams: self.num_cams + 1]
                 instance_feature = gather_rows(instance_feature, alloc.q2a)  # :438
                 anchor_embed2d = self.anchor_encoder2d(anchor2d)
                 ref_pts2d_list.append(anchor2d[..., :2])
@@ -226,6 +251,7 @@ class SimPBHead(BaseModule):
                     query3d=temp_attn_instance, query_pos3d=anchor_embed, anchor3d=anchor,
                     allocation=alloc, attn_mask=None, graph_model=self.graph_model)
                 self.instance_status = "3d"
+                self._m_live = None
             elif op == "qg_self_attn":
                 instance_feature = self.graph_model2d(i, query=instance_feature, value=instance_feature,
                                                       query_pos=anchor_embed2d, query_groups=ref_query_groups,
@@ -236,7 +262,8 @@ class SimPBHead(BaseModule):
                     enc = dict(encoder2d_dict, value=pre_values[i], value_is_projected=True)
                 instance_feature = layer(query=instance_feature, query_pos=anchor_embed2d,
                                          reference_points=anchor2d.unsqueeze(2), query_groups=ref_query_groups,
-                                         query_cam=alloc.query_cam, **enc)
+                                         query_cam=alloc.query_cam, m_live=self._m_live,
+                                         keep_parts=dense.ENABLED and self._next_is_ffn(i), **enc)
             elif op == "refine2d":
                 anchor2d, cls2d, depth2d, alpha2d = layer(instance_feature, anchor2d, anchor_embed2d, metas=metas,
                                                           query_groups=ref_query_groups)
@@ -255,7 +282,8 @@ class SimPBHead(BaseModule):
                                                     query_pos=anchor_embed, key_pos=temp_anchor_embed)
                 temp_attn_instance = instance_feature
             elif op == "deformable":
-                instance_feature = layer(instance_feature, anchor, anchor_embed, feature_maps, metas)
+                instance_feature = layer(instance_feature, anchor, anchor_embed, feature_maps, metas,
+                                         keep_parts=dense.ENABLED and self._next_is_ffn(i))
             elif op == "refine3d":
                 anchor, cls, qt = layer(
                     instance_feature, anchor, anchor_embed, time_interval=time_interval,

@@ -150,6 +150,44 @@ def mha_forward(attn, query, key, value, groups=None, same_qk=False, query_cam=N
     return F.linear(o, attn.out_proj.weight, attn.out_proj.bias)
 
 
+def fused_graph_attention(layer, pre, post, query, query_pos, key=None, key_pos=None, value=None, query_cam=None,
+                          group_start=None, m_live=None):
+    """graph_model / graph_model2d of the reference (simpb_head.py:298-321) around one attention
+    operator, as three launches: a grouped GEMM for the q/k/v projections reading `query | query_pos`
+    (and `key | key_pos`) in place with fc_before folded into the value rows, the flash attention
+    core, and one GEMM for post(identity + out_proj(o)) reading `o | query | query_pos`
+    (plugin/dense.py). Returns None when the call is not one of the forms the decoder uses, and the
+    caller takes the unfused route."""
+    from . import dense
+    from .ops import attention_f32
+    attn = getattr(layer, "attn", None)
+    if (not isinstance(attn, nn.MultiheadAttention) or not getattr(layer, "batch_first", False)
+            or not isinstance(post, nn.Linear) or post.bias is not None or query_pos is None
+            or query.shape != query_pos.shape or attn.in_proj_weight is None):
+        return None
+    e, h = attn.embed_dim, attn.num_heads
+    if e != 2 * query.shape[-1] or e != h * 64 or query.shape[-1] % 64:
+        return None
+    if value is not None and (not isinstance(pre, nn.Linear) or pre.bias is not None):
+        return None
+    if key is None:
+        if value is not None and value is not query:
+            return None
+        w, b = dense.fold_mha_in(attn, pre if value is not None else None, "qkv")
+        qkv = dense.linear([query, query_pos], w, b, m_live=m_live)
+        q, k, v = qkv[..., :e], qkv[..., e: 2 * e], qkv[..., 2 * e:]
+    else:
+        if key_pos is None or key.shape != key_pos.shape or (value is not None and value is not key) or query_cam is not None:
+            return None
+        wq, bq = dense.fold_mha_in(attn, None, "q")
+        wkv, bkv = dense.fold_mha_in(attn, pre if value is not None else None, "kv")
+        q, kv = dense.gemm(dense.job([query, query_pos], wq, bq), dense.job([key, key_pos], wkv, bkv))
+        k, v = kv[..., :e], kv[..., e:]
+    o = attention_f32(q, k, v, h, query_cam, group_start)
+    wo, bo = dense.fold_mha_out(attn, post)
+    return dense.report(post, dense.linear([o, query, query_pos], wo, bo, m_live=m_live))
+
+
 @ATTENTION.register_module()
 class MultiheadAttention(BaseModule):
     """mmcv.cnn.bricks.transformer.MultiheadAttention as the reference configures it

@@ -59,14 +59,17 @@ def compare_trace(got, g, prefix, rtol=2e-4, atol=2e-4, skip=(), allow_permutati
     checked. Float records use |a-b| <= atol + rtol*max|b| (sketches mix a row, so the scale of
     the whole record is the right yardstick); integer records must match exactly. With
     allow_permutation a record may also match as a SET of rows (see rows_match); integer records
-    that index instances are then compared as multisets."""
+    that index instances are then compared as multisets. `skip`: regular expressions of record
+    names that are not compared (values a fused block never materialises)."""
+    import re
     names = [k[len(prefix):] for k in g.files if k.startswith(prefix)]
     assert names, prefix
-    missing = [n for n in names if n not in got.items and not any(n.startswith(s) for s in skip)]
+    skipped = lambda n: any(re.search(s, n) for s in skip)  # noqa: E731
+    missing = [n for n in names if n not in got.items and not skipped(n)]
     assert not missing, f"trace records missing: {missing[:5]}"
     bad = []
     for n in names:
-        if any(n.startswith(s) for s in skip):
+        if skipped(n):
             continue
         a, b = np.asarray(got.items[n]), g[prefix + n]
         if a.shape != b.shape:
@@ -153,6 +156,9 @@ def compare_result(res, g, prefix, box_tol=1e-3, score_tol=1e-3):
 
 
 def _flat(x):
+    from simpb_amd.plugin.dense import Segments
+    if isinstance(x, Segments):  # an unmaterialised residual_mode="cat" result
+        return [x.materialize()]
     if torch.is_tensor(x):
         return [x]
     if isinstance(x, (list, tuple)):

@@ -1,0 +1,217 @@
+"""csrc/gemm.hip + plugin/dense.py: the grouped segment-input GEMM, the segmented LayerNorm and the
+weight folds. CPU part: the folds are exact algebra (checked in float64 against the unfused formulas
+of simpb_head.py:298-310 and blocks.py:384-393) and the row-view logic. GPU part: the kernels against
+float64 matmuls; the fused attention / FFN blocks against the unfused module route on the GPU.
+Tolerance for fp32 GEMMs: 2e-5 * max|ref| (both sides fp32-exact products, different summation order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from simpb_amd.plugin import dense
+
+
+def _mha(e=512, h=8, seed=0):
+    torch.manual_seed(seed)
+    attn = nn.MultiheadAttention(e, h)
+    with torch.no_grad():
+        attn.in_proj_bias.normal_(0, 0.1)
+        attn.out_proj.bias.normal_(0, 0.1)
+    return attn
+
+
+def test_rows2d_views():
+    base = torch.zeros(2, 10, 1536)
+    t, rows, ld = dense.rows2d(base[..., 512:1024])
+    assert t.data_ptr() == base[..., 512:1024].data_ptr() and rows == 20 and ld == 1536
+    ex = torch.zeros(10, 256)[None].expand(1, -1, -1)
+    t, rows, ld = dense.rows2d(ex)
+    assert rows == 10 and ld == 256 and t.data_ptr() == ex.data_ptr()
+    ex2 = torch.zeros(10, 256)[None].expand(2, -1, -1)   # stride-0 batch: must be copied
+    t, rows, ld = dense.rows2d(ex2)
+    assert rows == 20 and ld == 256 and t.is_contiguous()
+    odd = torch.zeros(4, 10, 256)[:, :5]                  # non-uniform row stride
+    t, rows, ld = dense.rows2d(odd)
+    assert rows == 20 and ld == 256 and t.is_contiguous()
+
+
+def test_fold_mha_matches_unfused_formula():
+    """graph_model (simpb_head.py:298-310): fc_after(cat(f, p) + out_proj(o)), v = in_proj_v(fc_before(f))."""
+    attn = _mha()
+    c, e = 256, 512
+    torch.manual_seed(1)
+    pre, post = nn.Linear(c, e, bias=False), nn.Linear(e, c, bias=False)
+    f, p, o = torch.randn(7, c).double(), torch.randn(7, c).double(), torch.randn(7, e).double()
+    w, b = dense.fold_mha_in(attn, pre, "qkv")
+    got = torch.cat([f, p], 1) @ w.double().t() + b.double()
+    x = torch.cat([f, p], 1)
+    W, B = attn.in_proj_weight.double(), attn.in_proj_bias.double()
+    want = torch.cat([x @ W[:e].t() + B[:e], x @ W[e:2 * e].t() + B[e:2 * e],
+                      (f @ pre.weight.double().t()) @ W[2 * e:].t() + B[2 * e:]], 1)
+    assert float((got - want).abs().max()) < 1e-5
+    wq, bq = dense.fold_mha_in(attn, None, "q")
+    wkv, bkv = dense.fold_mha_in(attn, pre, "kv")
+    assert torch.equal(wq, w[:e]) and torch.equal(wkv, w[e:]) and torch.equal(torch.cat([bq, bkv]), b)
+    # no fc_before: v = in_proj_v(cat)
+    w2, _ = dense.fold_mha_in(attn, None, "qkv")
+    assert torch.equal(w2, attn.in_proj_weight.detach())
+    wo, bo = dense.fold_mha_out(attn, post)
+    got = torch.cat([o, f, p], 1) @ wo.double().t() + bo.double()
+    want = (x + o @ attn.out_proj.weight.double().t() + attn.out_proj.bias.double()) @ post.weight.double().t()
+    assert float((got - want).abs().max()) < 1e-5
+
+
+def test_fold_cache_follows_parameter_updates():
+    attn = _mha(seed=3)
+    post = nn.Linear(512, 256, bias=False)
+    w0, _ = dense.fold_mha_out(attn, post)
+    assert dense.fold_mha_out(attn, post)[0] is w0          # cached
+    with torch.no_grad():
+        post.weight.mul_(2.0)                               # in-place update bumps the version
+    w1, _ = dense.fold_mha_out(attn, post)
+    assert w1 is not w0 and torch.allclose(w1, 2 * w0, rtol=1e-6, atol=1e-7)
+
+
+def test_fold_ffn_and_sum_input():
+    torch.manual_seed(2)
+    fc2, idfc, lin = nn.Linear(1024, 256), nn.Linear(512, 256), nn.Linear(256, 416)
+    h, x = torch.randn(5, 1024), torch.randn(5, 512)
+    w, b = dense.fold_ffn_out(fc2, idfc)
+    assert torch.allclose(torch.cat([h, x], 1) @ w.t() + b, fc2(h) + idfc(x), atol=1e-5)
+    a, c = torch.randn(5, 256), torch.randn(5, 256)
+    assert torch.allclose(torch.cat([a, c], 1) @ dense.fold_sum_input(lin).t() + lin.bias, lin(a + c), atol=1e-5)
+    w, b = dense.fold_stack("t", [nn.Linear(256, 8), nn.Linear(256, 4)], copies=2)
+    assert w.shape == (12, 512) and b.shape == (12,)
+
+
+# ---------------------------------------------------------------------------------------- GPU
+gpu = pytest.mark.gpu
+
+
+def _ref(xs, w, b, relu):
+    y = torch.cat([x.double().reshape(-1, x.shape[-1]) for x in xs], 1) @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    return y.clamp_min(0) if relu else y
+
+
+@gpu
+@pytest.mark.parametrize("m,n,ks,relu,bias", [
+    (900, 256, [512, 256, 256], False, True),    # attention output fold: 232 tiles of 32x32
+    (900, 1536, [256, 256], False, True),        # q|k|v projection: 64-wide tiles
+    (900, 1024, [512], True, True),              # FFN fc1 + ReLU
+    (900, 256, [1024, 512], False, True),        # FFN output fold, K = 1536
+    (900, 18, [256], False, True),               # learnable_fc: N < one tile
+    (6, 416, [256], False, False),               # camera logits: M < one tile
+    (1536, 384, [256, 256], False, True),        # MSDA offsets|weights
+    (33, 100, [64], True, False),                # ragged everything, single chunk
+    (65, 70, [64, 64, 64, 64], False, True),     # four segments
+])
+def test_gemm_vs_float64(m, n, ks, relu, bias):
+    rs = torch.Generator().manual_seed(m * 7 + n)
+    xs = [torch.randn(m, k, generator=rs) for k in ks]
+    w = torch.randn(n, sum(ks), generator=rs) / np.sqrt(sum(ks))
+    b = torch.randn(n, generator=rs) if bias else None
+    got = dense.linear([x.cuda() for x in xs], w.cuda(), b.cuda() if bias else None, relu=relu).cpu()
+    want = _ref(xs, w, b, relu)
+    assert got.shape == (m, n)
+    assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+@gpu
+def test_gemm_grouped_strided_and_m_live():
+    """Three problems in one launch; segments and outputs that are column ranges of wider buffers;
+    rows >= *m_live come back as zeros and rows below are untouched by the bound."""
+    g = torch.Generator().manual_seed(5)
+    wide = torch.randn(2, 50, 1536, generator=g).cuda()
+    pos = torch.randn(2, 50, 256, generator=g).cuda()
+    w0 = (torch.randn(512, 768, generator=g) / 28).cuda()
+    w1 = (torch.randn(96, 256, generator=g) / 16).cuda()
+    b1 = torch.randn(96, generator=g).cuda()
+    big = torch.randn(1, 700, 128, generator=g).cuda()
+    w2 = (torch.randn(64, 128, generator=g) / 11).cuda()
+    out1 = torch.full((2, 50, 200), 7.0, device="cuda")
+    live = torch.tensor([0, 0, 411], dtype=torch.int32, device="cuda")
+    y0, y1, y2 = dense.gemm(
+        dense.job([wide[..., 512:1024], pos], w0),
+        dense.job(pos, w1, b1, relu=True, out=out1[..., 100:196]),
+        dense.job(big, w2, m_live=live[2:3]))
+    want0 = _ref([wide[..., 512:1024].cpu(), pos.cpu()], w0.cpu(), None, False).reshape(2, 50, 512)
+    assert float((y0.cpu().double() - want0).abs().max()) <= 2e-5 * float(want0.abs().max())
+    want1 = _ref([pos.cpu()], w1.cpu(), b1.cpu(), True).reshape(2, 50, 96)
+    assert y1.data_ptr() == out1[..., 100:196].data_ptr()
+    assert float((out1[..., 100:196].cpu().double() - want1).abs().max()) <= 2e-5 * float(want1.abs().max())
+    assert bool((out1[..., :100] == 7.0).all()) and bool((out1[..., 196:] == 7.0).all())   # neighbours untouched
+    want2 = _ref([big.cpu()], w2.cpu(), None, False).reshape(1, 700, 64)
+    assert float((y2[:, :411].cpu().double() - want2[:, :411]).abs().max()) <= 2e-5 * float(want2.abs().max())
+    assert bool((y2[:, 411:] == 0).all())
+
+
+@gpu
+def test_gemm_rejects_bad_layouts():
+    x = torch.randn(8, 96, device="cuda")      # K not a multiple of 64
+    with pytest.raises(RuntimeError):
+        dense.linear(x, torch.randn(16, 96, device="cuda"))
+    with pytest.raises(RuntimeError):
+        dense.linear(torch.randn(8, 64), torch.randn(16, 64))   # CPU tensors: no fallback
+
+
+@gpu
+@pytest.mark.parametrize("ks", [[256], [256, 256], [64]])
+def test_layernorm_segments_vs_torch(ks):
+    g = torch.Generator().manual_seed(9)
+    xs = [(torch.randn(3, 301, k, generator=g) * 3 + 1.5) for k in ks]
+    ln = nn.LayerNorm(sum(ks))
+    with torch.no_grad():
+        ln.weight.normal_(1, 0.2, generator=g)
+        ln.bias.normal_(0, 0.2, generator=g)
+    want = ln.double()(torch.cat(xs, -1).double())
+    ln = ln.float().cuda()
+    got = dense.layernorm([x.cuda() for x in xs], ln).cpu()
+    assert float((got.double() - want).abs().max()) < 2e-5
+    live = torch.tensor([500], dtype=torch.int32, device="cuda")
+    got = dense.layernorm([x.cuda() for x in xs], ln, m_live=live).cpu().reshape(-1, sum(ks))
+    assert float((got[:500].double() - want.reshape(-1, sum(ks))[:500]).abs().max()) < 2e-5 and bool((got[500:] == 0).all())
+
+
+@gpu
+def test_fused_graph_attention_matches_unfused_route():
+    """The three-launch block against the module route (cat, fc_before, nn.MultiheadAttention
+    arithmetic, + identity, fc_after) on the GPU, for the three call forms of the decoder."""
+    from simpb_amd.plugin.layers import MultiheadAttention, fused_graph_attention
+    torch.manual_seed(11)
+    layer = MultiheadAttention(512, 8, batch_first=True, dropout=0.1).cuda().eval()
+    with torch.no_grad():
+        layer.attn.in_proj_bias.normal_(0, 0.1)
+        layer.attn.out_proj.bias.normal_(0, 0.1)
+    pre, post = nn.Linear(256, 512, bias=False).cuda(), nn.Linear(512, 256, bias=False).cuda()
+    f, p = torch.randn(1, 900, 256, device="cuda"), torch.randn(1, 900, 256, device="cuda")
+    tf, tp = torch.randn(1, 600, 256, device="cuda"), torch.randn(1, 600, 256, device="cuda")
+
+    def unfused(query, key, value, qp, kp):
+        q = torch.cat([query, qp], -1)
+        k = torch.cat([key, kp], -1) if key is not None else None
+        v = pre(value) if value is not None else None
+        return post(layer(q, k, v))
+
+    with torch.no_grad():
+        for query, key, value, kp in [(f, None, f, None), (f, tf, tf, tp), (f, None, None, None)]:
+            got = fused_graph_attention(layer, pre, post, query, p, key, kp, value)
+            want = unfused(query, key, value, p, kp)
+            assert got is not None
+            assert float((got - want).abs().max()) <= 5e-5 * max(1.0, float(want.abs().max()))
+
+
+@gpu
+def test_fused_ffn_matches_unfused_route():
+    from simpb_amd.plugin.blocks import AsymmetricFFN
+    torch.manual_seed(12)
+    ffn = AsymmetricFFN(in_channels=512, pre_norm=dict(type="LN"), embed_dims=256, feedforward_channels=1024,
+                        num_fcs=2, ffn_drop=0.1, act_cfg=dict(type="ReLU", inplace=True)).cuda().eval()
+    a, b = torch.randn(1, 900, 256, device="cuda"), torch.randn(1, 900, 256, device="cuda")
+    with torch.no_grad():
+        got = ffn(dense.Segments([a, b]))
+        x = ffn.pre_norm(torch.cat([a, b], -1))
+        want = ffn.identity_fc(x) + ffn.layers(x)
+    assert float((got - want).abs().max()) <= 5e-5 * max(1.0, float(want.abs().max()))

@@ -12,10 +12,24 @@ from tests.helpers import (attach_trace_hooks, build_product_head, compare_resul
 pytestmark = pytest.mark.gpu
 
 
-def run_product_stream(g, frames=None):
-    from simpb_amd.plugin import ops
+# Records of the reference's module boundaries that the fused decoder never materialises: the output
+# of an attention operator before fc_after (identity + out_proj(o), folded into one product with
+# fc_after: plugin/dense.py). Everything downstream of them (fc_after, norm, ...) is compared.
+FOLDED_AWAY = (r"^L\d+\.(gnn|temp_gnn|qg_self_attn)\.",)
+
+
+def run_product_stream(g, frames=None, fused=True):
+    from simpb_amd.plugin import dense, ops
     spec = spec_of(g)
     head = build_product_head(spec)
+    dense.ENABLED = fused
+    try:
+        yield from _run_stream(head, spec, frames, ops)
+    finally:
+        dense.ENABLED = True
+
+
+def _run_stream(head, spec, frames, ops):
     with torch.no_grad():
         for f in range(spec["frames"] if frames is None else frames):
             trace = synth.Trace()
@@ -29,17 +43,21 @@ def run_product_stream(g, frames=None):
             yield f, trace, outs, res, head
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
 @pytest.mark.parametrize("name", ["head_small.npz", "head_r50.npz"])
-def test_head_stream_vs_golden(name):
+def test_head_stream_vs_golden(name, fused):
+    """fused: the product route (grouped GEMMs with folded weights). unfused: one vendor GEMM per
+    nn.Linear, where every module boundary of the reference exists and is compared."""
     g = load_golden(name)
     spec = spec_of(g)
-    for f, trace, outs, res, head in run_product_stream(g):
+    for f, trace, outs, res, head in run_product_stream(g, fused=fused):
         pre = f"f{f}."
         assert [x.shape[1] for x in outs["prediction2d"]] == g[pre + "n2#0"].tolist()
         if f in spec["trace_frames"]:
             # frame 0 has no temporal instances: records must match position by position; later
             # frames may hold the bank's instances in a different (tie-broken) order
-            compare_trace(trace, g, pre + "trace.", rtol=1e-3, atol=1e-3, allow_permutation=f > 0)
+            compare_trace(trace, g, pre + "trace.", rtol=1e-3, atol=1e-3, allow_permutation=f > 0,
+                          skip=FOLDED_AWAY if fused else ())
         bank = head.instance_bank
         for b in range(spec["bs"]):
             assert rows_match(bank.cached_anchor[b].cpu().numpy(), g[pre + "bank.cached_anchor#0"][b], 1e-3)
