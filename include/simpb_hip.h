@@ -124,6 +124,11 @@ typedef struct simpb_gemm_job {
   float* y;
   const int* m_live;
   int ldw, ldy, relu, reserved;
+  /* optional rank-1 term before the ReLU: rows with row_flag[row] != 0 also get bias2[col]. This is
+   * the 257th input column of ReWeight.reduce (models/aggregation.py:19-21,71-72: Linear over
+   * cat(query2d, is_center)) without materialising the concatenation. Both NULL = absent. */
+  const int* row_flag;
+  const float* bias2;
 } simpb_gemm_job;
 typedef struct simpb_gemm_args {
   int num_jobs;
@@ -167,7 +172,7 @@ int simpb_attention_f32(float* out, const float* q, const float* k, const float*
                         int num_key, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
 
 /* Fused small-MLP chains: a whole `linear_relu_ln` stack (models/blocks.py:32-43) -- [Linear, ReLU]*,
- * LayerNorm, ..., optional last Linear and Scale -- in one launch; up to 4 independent chains over
+ * LayerNorm, ..., optional last Linear and Scale -- in one launch; up to 8 independent chains over
  * the same rows share it (e.g. the pos/size/yaw/vel branches of SparseBox3DEncoder,
  * models/detection3d/blocks.py:57-74). The argument block is a plain host struct of device
  * pointers and sizes. Every width <= 256.
@@ -178,9 +183,19 @@ int simpb_attention_f32(float* out, const float* q, const float* k, const float*
  *                 IN_SINE2D  x f32 rows holding (x, y) in [0,1] at columns 0,1; the 256-d sine embedding
  *                            of models/utils.py:40-63 (cat(pos_y, pos_x)) is computed in the kernel
  *   chain output: out rows of the last width, row stride ldo; out_scale (or NULL) multiplies column-wise
- *                 (mmcv Scale after the last Linear) */
+ *                 (mmcv Scale after the last Linear); then the optional `post` stage on v = out[row, t]:
+ *     POST_REFINE3D  SparseBox3DRefinementModule.forward (models/detection3d/blocks.py:133-143):
+ *                    v = (t >= div_col0 ? v / div[row / div_rows] : v) + res[row, t]   (res = anchor, ldres)
+ *     POST_REFINE2D  SparseBox2DRefinementModule.forward (models/detection2d/blocks.py:122-125, 144):
+ *                    v = sigmoid(v + (t < res_cols ? inverse_sigmoid(res[row, t]) : 0))   (res = anchor2d;
+ *                    inverse_sigmoid of models/utils.py:4-8, eps 1e-5)
+ *     POST_SIGMOID   v = sigmoid(v)   (ReWeight.alpha, models/aggregation.py:23-24) */
 #define SIMPB_MLP_MAX_OPS 12
-#define SIMPB_MLP_MAX_CHAINS 4
+#define SIMPB_MLP_MAX_CHAINS 8
+#define SIMPB_MLP_POST_NONE 0
+#define SIMPB_MLP_POST_REFINE3D 1
+#define SIMPB_MLP_POST_REFINE2D 2
+#define SIMPB_MLP_POST_SIGMOID 3
 #define SIMPB_MLP_LINEAR 0
 #define SIMPB_MLP_LAYERNORM 1
 #define SIMPB_MLP_IN_ROWS 0
@@ -196,6 +211,9 @@ typedef struct simpb_mlp_chain {
   float* out;
   const float* out_scale;
   int ldx, ldx2, ldo, in_dim, in_mode, n_ops;
+  int post, ldres, res_cols, div_rows, div_col0, reserved;
+  const float* res;
+  const float* div;
   simpb_mlp_op ops[SIMPB_MLP_MAX_OPS];
 } simpb_mlp_chain;
 typedef struct simpb_mlp_args {
@@ -205,6 +223,29 @@ typedef struct simpb_mlp_args {
   simpb_mlp_chain chain[SIMPB_MLP_MAX_CHAINS];
 } simpb_mlp_args;
 int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream);
+
+/* out[row] = sigmoid(dot(x[row, 0:k], w) + b[0]) : ReWeight.alpha (models/aggregation.py:23-24:
+ * Linear(f_dim, 1) + Sigmoid) over rows of stride ldx. Rows >= *m_live (may be NULL) get 0. k % 4 == 0. */
+int simpb_rowdot_sigmoid(float* out, const float* x, int ldx, const float* w, const float* b, int num_rows, int k,
+                         const int* m_live, void* stream);
+
+/* SparseBox3DKeyPointsGenerator.anchor_projection (models/detection3d/blocks.py:248-280) for one
+ * transform: out[b, a] = anchor[b, a] with centre = R (centre - vel * time_interval[b]) + t (time_interval
+ * may be NULL), velocity = R vel, size kept, and the yaw pair handled exactly as written there (:271-278:
+ * the 2x2 block applied to [cos, sin], stored into the [sin, cos] slots in that order). This is what
+ * InstanceBank.get (models/instance_bank.py:98-101) runs on the 600 cached anchors at the start of every
+ * frame. anchor/out f32 [bs, A, 11]; T_src2dst f32 [bs, 4, 4] row-major; time_interval f32 [bs]. */
+int simpb_anchor_projection(float* out, const float* anchor, const float* T_src2dst, const float* time_interval,
+                            int batch_size, int num_anchors, void* stream);
+
+/* Operands of simpb_ms_deform_attn_grouped_forward from the raw projections (models/group_attn.py:181-201):
+ * raw rows (stride ldraw) = [sampling_offsets heads*L*P*2 | attention logits heads*L*P];
+ * attn_weight = softmax over the L*P logits of each head; sampling_loc = ref[row, 0:2] + offset / (W_l, H_l).
+ * ref rows have stride ldref (the 2-d reference points, simpb_head.py:523); spatial_shapes i64 [L, 2] = (H, W).
+ * Rows >= *m_live (may be NULL) get zeros. Outputs in the layouts of simpb_ms_deform_attn_grouped_forward. */
+int simpb_msda_prep(float* sampling_loc, float* attn_weight, const float* raw, int ldraw, const float* ref, int ldref,
+                    const long long* spatial_shapes, int num_rows, int num_heads, int num_levels, int num_points,
+                    const int* m_live, void* stream);
 
 /* Sampling locations of the 3D deformable aggregation in its own layout: key points of
  * SparseBox3DKeyPointsGenerator.forward (models/detection3d/blocks.py:181-222: num_fix fixed scales x

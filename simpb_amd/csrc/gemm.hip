@@ -11,9 +11,11 @@
 //
 // Shape of the problem: M ~ 1 k, N and K in 256..1 536. A 64x256 tile (csrc/linear.hip, built for
 // the 90 k-row value projection) would give 15-60 workgroups on a 256-CU chip, so the tile here is
-// 32 x 32 (or 32 x 64) and the FOUR WAVES OF A WORKGROUP SPLIT K: each wave owns the whole output
-// tile over a quarter (half) of every 64-wide K chunk, so no operand is read from LDS twice, and the
-// partial tiles meet once in LDS at the end. M = 900, N = 256 is 232 workgroups.
+// 32 x 32 (or 32 x 64) and the EIGHT WAVES OF A WORKGROUP SPLIT K: each wave owns a whole 32 x 32
+// output tile over an eighth (quarter) of every 64-wide K chunk, so no operand is read from LDS
+// twice, and the partial tiles meet once in LDS at the end. M = 900, N = 256 is 232 workgroups; two
+// waves per SIMD let one wave's staging instructions run under the other's matrix instructions
+// (measured with one wave per SIMD: the matrix pipe was 30-47 % busy, the waves 30 % in issue).
 //
 //  * X is given as up to four COLUMN SEGMENTS (pointer, row stride, width): y = [x0 | x1 | ...] W^T.
 //    That is how cat([feature, pos_embed]) (simpb_head.py:299-301), the `identity +` branches and the
@@ -21,11 +23,12 @@
 //  * Up to four independent problems share a launch (q / kv projections of the temporal attention).
 //  * `m_live` (device int, optional): rows >= *m_live are capacity slots of the static 2D query set;
 //    they are written as zeros without touching X or W.
-//  * Two K chunks are kept in flight in registers ahead of the one being multiplied; LDS is double
-//    buffered, one barrier per chunk.
+//  * Four K chunks are kept in flight in registers ahead of the one being multiplied (all loads
+//    unconditional, so the waits are counted); LDS is double buffered, one barrier per chunk.
 //  * Workgroups are numbered so that each XCD (blockIdx % 8) walks a contiguous range of tiles:
 //    neighbouring tiles share their X rows in that XCD's L2.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/simpb_hip.h"
 
 extern "C" int simpb_check_launch(void);
@@ -33,9 +36,22 @@ extern "C" int simpb_check_launch(void);
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;  // native vector: plain loads/stores, no struct memcpy
 
 constexpr int BM = 32, BK = 64, LDK = BK + 4;
-constexpr int kThreads = 256;
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+
+// compile-time loop: the register-set index must be a constant in the front end already, or the
+// prefetch arrays are not promoted to registers (they were placed in scratch with a plain
+// `#pragma unroll` loop over lambdas)
+template <int D, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (D < N) {
+    f(std::integral_constant<int, D>{});
+    static_for<D + 1, N>(f);
+  }
+}
 
 struct GemmLaunch {
   simpb_gemm_args a;
@@ -43,16 +59,20 @@ struct GemmLaunch {
   int per_xcd;  // tiles per XCD range
 };
 
-template <int BN>
+template <int BN, int DEPTH>
 __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
-  constexpr int WN = BN / 32;         // waves across N
-  constexpr int WK = 4 / WN;          // waves across K
-  constexpr int KW = BK / WK;         // k values of a chunk per wave
-  constexpr int KH = KW / 2;          // ... per lane half
-  constexpr int NW4 = BN / 16;        // float4 W loads per thread per chunk
+  static_assert(DEPTH % 2 == 0, "LDS buffer index = register set index & 1");
+  constexpr int WN = BN / 32;             // waves across N
+  constexpr int WK = kWaves / WN;         // waves across K
+  constexpr int KW = BK / WK;             // k values of a chunk per wave
+  constexpr int KH = KW / 2;              // ... per lane half
+  constexpr int NX4 = BM * 16 / kThreads; // 16-byte X loads per thread per chunk
+  constexpr int NW4 = BN * 16 / kThreads; // 16-byte W loads per thread per chunk
+  constexpr int RS = kThreads / 16;       // rows covered by one pass of the staging threads
   constexpr int LDP = BN + 1;
   constexpr int kStage = 2 * (BM + BN) * LDK;
   constexpr int kPart = WK * BM * LDP;
+  static_assert(KH % 4 == 0 && NX4 >= 1 && NW4 >= 1, "tile / wave split");
   __shared__ float smem[kStage > kPart ? kStage : kPart];
   float* s_x = smem;                     // [2][BM][LDK]
   float* s_w = smem + 2 * BM * LDK;      // [2][BN][LDK]
@@ -87,46 +107,65 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
   const int r32 = lane & 31, half = lane >> 5;
   const int wn = wave % WN, wk = wave / WN;
 
-  // ---- staging: thread f -> (row f >> 4, float4 column f & 15) of a [rows][64] chunk
+  // ---- staging: thread f -> (row f >> 4, 16-byte column f & 15) of a [rows][64] chunk. Loads are
+  // UNCONDITIONAL (row / column indices clamped; the surplus rows and columns of an edge tile are
+  // computed on repeated data and never stored): a load behind a branch makes the compiler wait for
+  // every outstanding load (vmcnt(0)) instead of the oldest register set only. Addresses are a
+  // wave-uniform base (segment pointer + k offset, scalar registers) plus a per-thread 32-bit offset
+  // that does not change along K.
   const int sr = tid >> 4, sc4 = tid & 15;
-  float4 px[2][2], pw[2][NW4];
+  f32x4 px[DEPTH][NX4], pw[DEPTH][NW4];
   const float* __restrict__ w = job.w;
+  unsigned xrow[NX4], wofs[NW4];
+#pragma unroll
+  for (int i = 0; i < NX4; ++i) xrow[i] = (unsigned)min(row0 + sr + RS * i, live - 1);
+#pragma unroll
+  for (int i = 0; i < NW4; ++i) wofs[i] = (unsigned)min(col0 + sr + RS * i, N - 1) * (unsigned)job.ldw + sc4 * 4;
+  const int nchunks = K / BK;
+  const float* const x0 = job.x[0];
+  const float* const x1 = job.x[1];
+  const float* const x2 = job.x[2];
+  const float* const x3 = job.x[3];
+  const int e1 = job.kseg[0], e2 = e1 + (job.num_seg > 1 ? job.kseg[1] : 0), e3 = e2 + (job.num_seg > 2 ? job.kseg[2] : 0);
+  const unsigned l0 = job.ldx[0], l1 = job.ldx[1], l2 = job.ldx[2], l3 = job.ldx[3];
 
-  // segment walk state per register set is recomputed from the chunk index (<= 4 segments)
-  auto fetch = [&](int set, int k0) {
-    int seg = 0, koff = k0;
-#pragma unroll
-    for (int s = 0; s < SIMPB_GEMM_MAX_SEGS - 1; ++s)
-      if (seg == s && s + 1 < job.num_seg && koff >= job.kseg[s]) { koff -= job.kseg[s]; seg = s + 1; }
-    const float* __restrict__ xs = job.x[seg];
-    const int ldx = job.ldx[seg];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int gr = row0 + sr + 16 * i;
-      px[set][i] = gr < live ? *reinterpret_cast<const float4*>(xs + (size_t)gr * ldx + koff + sc4 * 4)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < NW4; ++i) {
-      const int gc = col0 + sr + 16 * i;
-      pw[set][i] = gc < N ? *reinterpret_cast<const float4*>(w + (size_t)gc * job.ldw + k0 + sc4 * 4)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+  auto fetch = [&](auto set_c, int chunk) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    const int k0 = min(chunk, nchunks - 1) * BK;
+    // segment of this chunk (scalar selects; segment widths are multiples of the chunk)
+    const float* xs = x0 + k0;
+    unsigned ldx = l0;
+    if (k0 >= e1) { xs = x1 + (k0 - e1); ldx = l1; }
+    if (k0 >= e2) { xs = x2 + (k0 - e2); ldx = l2; }
+    if (k0 >= e3) { xs = x3 + (k0 - e3); ldx = l3; }
+    const float* wk0 = w + k0;
+    static_for<0, NX4>([&](auto i) __attribute__((always_inline)) {
+      px[set][decltype(i)::value] = *reinterpret_cast<const f32x4*>(xs + (xrow[decltype(i)::value] * ldx + sc4 * 4));
+    });
+    static_for<0, NW4>([&](auto i) __attribute__((always_inline)) {
+      pw[set][decltype(i)::value] = *reinterpret_cast<const f32x4*>(wk0 + wofs[decltype(i)::value]);
+    });
   };
-  auto stash = [&](int set, int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<float4*>(&s_x[(buf * BM + sr + 16 * i) * LDK + sc4 * 4]) = px[set][i];
-#pragma unroll
-    for (int i = 0; i < NW4; ++i)
-      *reinterpret_cast<float4*>(&s_w[(buf * BN + sr + 16 * i) * LDK + sc4 * 4]) = pw[set][i];
+  auto stash = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    constexpr int buf = set & 1;
+    static_for<0, NX4>([&](auto i) __attribute__((always_inline)) {
+      constexpr int ii = decltype(i)::value;
+      *reinterpret_cast<f32x4*>(&s_x[(buf * BM + sr + RS * ii) * LDK + sc4 * 4]) = px[set][ii];
+    });
+    static_for<0, NW4>([&](auto i) __attribute__((always_inline)) {
+      constexpr int ii = decltype(i)::value;
+      *reinterpret_cast<f32x4*>(&s_w[(buf * BN + sr + RS * ii) * LDK + sc4 * 4]) = pw[set][ii];
+    });
   };
 
-  f32x16 acc;
+  // two accumulators per wave (even / odd k steps): consecutive matrix instructions of a wave do not
+  // depend on each other; they are added once at the end
+  f32x16 acc, acc_odd;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_odd[r] = 0.f; }
 
-  auto multiply = [&](int buf) {
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
     // lane (r32, half) holds k = wk*KW + half*KH + 0..KH-1 of its x row and of its W row: the same
     // permutation of k on both operands, so the product is unchanged and both arrive as b128 reads
     const float* ax = &s_x[(buf * BM + r32) * LDK + wk * KW + half * KH];
@@ -140,29 +179,40 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
       b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
     }
 #pragma unroll
-    for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    for (int s = 0; s < KH; s += 2) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+      acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s + 1], b[s + 1], acc_odd, 0, 0, 0);
+    }
   };
 
-  const int nchunks = K / BK;
-  fetch(0, 0);
-  if (nchunks > 1) fetch(1, BK);
-  for (int c = 0; c < nchunks; c += 2) {
-    stash(0, 0);
-    __syncthreads();
-    if (c + 2 < nchunks) fetch(0, (c + 2) * BK);
-    multiply(0);
-    if (c + 1 < nchunks) {
-      stash(1, 1);
+  // DEPTH register sets = DEPTH chunks in flight ahead of the one being multiplied: the operands
+  // come from the Infinity Cache / HBM (activations were just written by another XCD, and every
+  // workgroup walks K in step, so a chunk is a first touch for all of them at once).
+  static_for<0, DEPTH>([&](auto d) __attribute__((always_inline)) { fetch(d, decltype(d)::value); });
+  const int groups = nchunks / DEPTH;
+  for (int g = 0; g < groups; ++g) {
+    static_for<0, DEPTH>([&](auto d) __attribute__((always_inline)) {
+      stash(d);
       __syncthreads();
-      if (c + 3 < nchunks) fetch(1, (c + 3) * BK);
-      multiply(1);
-    }
+      fetch(d, (g + 1) * DEPTH + decltype(d)::value);  // past the end: the last chunk again, never used
+      multiply(decltype(d)::value & 1);
+    });
   }
+  const int rem = nchunks - groups * DEPTH;
+  static_for<0, DEPTH - 1>([&](auto d) __attribute__((always_inline)) {
+    if (decltype(d)::value < rem) {
+      stash(d);
+      __syncthreads();
+      multiply(decltype(d)::value & 1);
+    }
+  });
 
   // ---- the WK partial tiles meet in LDS (C/D layout of the 32x32 tile: column = lane & 31,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
   __syncthreads();
   float* part = smem;  // [WK][BM][LDP]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc_odd[r];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -178,6 +228,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
 #pragma unroll
       for (int p = 1; p < WK; ++p) v += part[(p * BM + r) * LDP + c];  // fixed order: deterministic
       if (bias) v += bias[gc];
+      if (job.row_flag && job.row_flag[gr]) v += job.bias2[gc];
       if (job.relu) v = fmaxf(v, 0.f);
       y[(size_t)gr * job.ldy + gc] = gr < live ? v : 0.f;
     }
@@ -239,6 +290,7 @@ extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
     if (!job.y || !job.w || job.M <= 0 || job.N <= 0 || job.K <= 0 || job.K % BK) return SIMPB_EINVAL;
     if (job.num_seg <= 0 || job.num_seg > SIMPB_GEMM_MAX_SEGS || job.ldy < job.N || job.ldw < job.K) return SIMPB_EINVAL;
     if ((reinterpret_cast<size_t>(job.w) & 15) || (job.ldw & 3)) return SIMPB_EINVAL;
+    if ((job.row_flag != nullptr) != (job.bias2 != nullptr)) return SIMPB_EINVAL;
     int ksum = 0;
     for (int s = 0; s < job.num_seg; ++s) {
       if (!job.x[s] || job.kseg[s] <= 0 || job.kseg[s] % BK || job.ldx[s] < job.kseg[s] || (job.ldx[s] & 3) ||
@@ -262,9 +314,9 @@ extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
   dim3 grid(L.per_xcd * 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (bn == 64)
-    hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(kThreads), 0, s, L);
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 4>), grid, dim3(kThreads), 0, s, L);
   else
-    hipLaunchKernelGGL(gemm_f32_kernel<32>, grid, dim3(kThreads), 0, s, L);
+    hipLaunchKernelGGL((gemm_f32_kernel<32, 4>), grid, dim3(kThreads), 0, s, L);
   return simpb_check_launch();
 }
 

@@ -20,6 +20,24 @@ namespace {
 
 constexpr int kMaxDim = 256;
 
+// optional last stage on one output value (see SIMPB_MLP_POST_* in the header)
+__device__ __forceinline__ float post_stage(const simpb_mlp_chain& ch, float v, int row, int t) {
+  if (ch.post == SIMPB_MLP_POST_REFINE3D) {
+    if (ch.div && t >= ch.div_col0) v = v / ch.div[row / ch.div_rows];
+    if (t < ch.res_cols) v += ch.res[(size_t)row * ch.ldres + t];
+  } else if (ch.post == SIMPB_MLP_POST_REFINE2D) {
+    if (t < ch.res_cols) {
+      float a = ch.res[(size_t)row * ch.ldres + t];
+      a = fminf(fmaxf(a, 0.f), 1.f);
+      v += logf(fmaxf(a, 1e-5f) / fmaxf(1.f - a, 1e-5f));
+    }
+    v = 1.f / (1.f + expf(-v));
+  } else if (ch.post == SIMPB_MLP_POST_SIGMOID) {
+    v = 1.f / (1.f + expf(-v));
+  }
+  return v;
+}
+
 template <int R, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void mlp_chain_kernel(simpb_mlp_args args) {
   constexpr int kThreads = WAVES * 64;
@@ -202,6 +220,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_chain_kernel(simpb_mlp_args ar
     if (row < N) {
       float v = act[cur][r][t];
       if (ch.out_scale) v *= ch.out_scale[t];
+      if (ch.post) v = post_stage(ch, v, row, t);
       ch.out[(size_t)row * ch.ldo + t] = v;
     }
   }
@@ -365,6 +384,7 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
     if (row < N) {
       float v = act[cur][r][t];
       if (ch.out_scale) v *= ch.out_scale[t];
+      if (ch.post) v = post_stage(ch, v, row, t);
       ch.out[(size_t)row * ch.ldo + t] = v;
     }
   }
@@ -380,6 +400,10 @@ extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream)
     if (!ch.x || !ch.out || ch.n_ops < 0 || ch.n_ops > SIMPB_MLP_MAX_OPS) return SIMPB_EINVAL;
     int width = ch.in_mode == SIMPB_MLP_IN_SINE2D ? 256 : ch.in_dim;
     if (width <= 0 || width > kMaxDim) return SIMPB_EINVAL;
+    if (ch.post < 0 || ch.post > SIMPB_MLP_POST_SIGMOID) return SIMPB_EINVAL;
+    if ((ch.post == SIMPB_MLP_POST_REFINE3D || ch.post == SIMPB_MLP_POST_REFINE2D) && (!ch.res || ch.ldres < ch.res_cols))
+      return SIMPB_EINVAL;
+    if (ch.post == SIMPB_MLP_POST_REFINE3D && ch.div && ch.div_rows <= 0) return SIMPB_EINVAL;
     if (ch.in_mode == SIMPB_MLP_IN_SINE2D && ch.ldx < 2) return SIMPB_EINVAL;
     for (int o = 0; o < ch.n_ops; ++o) {
       const simpb_mlp_op& op = ch.ops[o];

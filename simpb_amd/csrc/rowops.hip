@@ -1,0 +1,140 @@
+// Small row-wise kernels of the decoder that replace runs of 5-12 elementwise PyTorch launches each
+// (gfx950). None of them is bandwidth- or FLOP-relevant; what they remove is launch count on the
+// decoder's critical path (each such launch is 2-5 us of dependent latency in the replayed frame).
+#include <hip/hip_runtime.h>
+#include "../../include/simpb_hip.h"
+
+extern "C" int simpb_check_launch(void);
+
+namespace {
+
+// ---- SparseBox3DKeyPointsGenerator.anchor_projection
+// (/root/reference/projects/mmdet3d_plugin/models/detection3d/blocks.py:248-280), one thread per
+// anchor: centre moved by -vel * dt then through [R | t], size kept, velocity rotated, and the
+// yaw pair rotated AS WRITTEN THERE (:271-278): the 2x2 block is applied to [cos, sin] and the
+// result is stored back into the [sin, cos] slots in that order.
+__global__ __launch_bounds__(256) void anchor_projection_kernel(float* __restrict__ out, const float* __restrict__ anchor,
+                                                                const float* __restrict__ T, const float* __restrict__ dt,
+                                                                int bs, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs * n) return;
+  const int b = i / n;
+  const float* a = anchor + (size_t)i * 11;
+  const float* m = T + (size_t)b * 16;
+  float cx = a[0], cy = a[1], cz = a[2];
+  const float vx = a[8], vy = a[9], vz = a[10];
+  if (dt) {
+    const float t = dt[b];
+    cx -= vx * t; cy -= vy * t; cz -= vz * t;
+  }
+  float* o = out + (size_t)i * 11;
+  // matmul(T[:3,:3], c) + T[:3,3]: products summed left to right like the batched matmul
+  o[0] = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
+  o[1] = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
+  o[2] = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
+  o[3] = a[3]; o[4] = a[4]; o[5] = a[5];
+  const float s = a[6], c = a[7];
+  o[6] = m[0] * c + m[1] * s;
+  o[7] = m[4] * c + m[5] * s;
+  o[8] = m[0] * vx + m[1] * vy + m[2] * vz;
+  o[9] = m[4] * vx + m[5] * vy + m[6] * vz;
+  o[10] = m[8] * vx + m[9] * vy + m[10] * vz;
+}
+
+// ---- operands of the grouped multi-scale deformable attention from the fused projection
+// (group_attn.py:181-201): one thread per (query slot, head). raw row = [offsets heads*L*P*2 |
+// logits heads*L*P]; attention = softmax over the L*P logits of the head; location = reference point
+// + offset / (W_l, H_l).
+__global__ __launch_bounds__(256) void msda_prep_kernel(float* __restrict__ loc, float* __restrict__ attn,
+                                                        const float* __restrict__ raw, int ldraw,
+                                                        const float* __restrict__ ref, int ldref,
+                                                        const long long* __restrict__ spatial_shapes, int rows,
+                                                        int heads, int L, int P, const int* __restrict__ m_live) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * heads) return;
+  const int q = i / heads, h = i - q * heads;
+  const int LP = L * P;
+  float* lo = loc + (size_t)i * LP * 2;
+  float* at = attn + (size_t)i * LP;
+  const int live = m_live ? *m_live : rows;
+  if (q >= live) {  // capacity slot: defined values, never sampled (query_cam = -1)
+    for (int j = 0; j < LP; ++j) { lo[2 * j] = 0.f; lo[2 * j + 1] = 0.f; at[j] = 0.f; }
+    return;
+  }
+  const float* off = raw + (size_t)q * ldraw + h * LP * 2;
+  const float* lg = raw + (size_t)q * ldraw + heads * LP * 2 + h * LP;
+  const float rx = ref[(size_t)q * ldref], ry = ref[(size_t)q * ldref + 1];
+  float mx = lg[0];
+  for (int j = 1; j < LP; ++j) mx = fmaxf(mx, lg[j]);
+  float sum = 0.f;
+  for (int j = 0; j < LP; ++j) sum += expf(lg[j] - mx);
+  const float inv = 1.f / sum;
+  for (int l = 0; l < L; ++l) {
+    const float Hf = (float)spatial_shapes[2 * l], Wf = (float)spatial_shapes[2 * l + 1];
+    for (int p = 0; p < P; ++p) {
+      const int j = l * P + p;
+      lo[2 * j] = rx + off[2 * j] / Wf;
+      lo[2 * j + 1] = ry + off[2 * j + 1] / Hf;
+      at[j] = expf(lg[j] - mx) * inv;
+    }
+  }
+}
+
+// ---- ReWeight.alpha (aggregation.py:23-24): one wave per row
+__global__ __launch_bounds__(256) void rowdot_sigmoid_kernel(float* __restrict__ out, const float* __restrict__ x, int ldx,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             int rows, int k, const int* __restrict__ m_live) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int live = m_live ? *m_live : rows;
+  if (row >= live) {
+    if (lane == 0) out[row] = 0.f;
+    return;
+  }
+  float s = 0.f;
+  for (int c = lane * 4; c < k; c += 256) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
+    const float4 wv = *reinterpret_cast<const float4*>(w + c);
+    s += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) out[row] = 1.f / (1.f + expf(-(s + (b ? b[0] : 0.f))));
+}
+
+}  // namespace
+
+extern "C" int simpb_rowdot_sigmoid(float* out, const float* x, int ldx, const float* w, const float* b, int num_rows,
+                                    int k, const int* m_live, void* stream) {
+  if (!out || !x || !w || num_rows <= 0 || k <= 0 || (k & 3) || ldx < k || (ldx & 3)) return SIMPB_EINVAL;
+  if ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w)) & 15) return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(rowdot_sigmoid_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), out, x,
+                     ldx, w, b, num_rows, k, m_live);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_anchor_projection(float* out, const float* anchor, const float* T_src2dst, const float* time_interval,
+                                       int batch_size, int num_anchors, void* stream) {
+  if (!out || !anchor || !T_src2dst || batch_size <= 0 || num_anchors <= 0) return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  const int total = batch_size * num_anchors;
+  hipLaunchKernelGGL(anchor_projection_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     out, anchor, T_src2dst, time_interval, batch_size, num_anchors);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_msda_prep(float* sampling_loc, float* attn_weight, const float* raw, int ldraw, const float* ref,
+                               int ldref, const long long* spatial_shapes, int num_rows, int num_heads, int num_levels,
+                               int num_points, const int* m_live, void* stream) {
+  if (!sampling_loc || !attn_weight || !raw || !ref || !spatial_shapes || num_rows <= 0 || num_heads <= 0 ||
+      num_levels <= 0 || num_points <= 0 || ldraw < num_heads * num_levels * num_points * 3 || ldref < 2)
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  const int total = num_rows * num_heads;
+  hipLaunchKernelGGL(msda_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     sampling_loc, attn_weight, raw, ldraw, ref, ldref, spatial_shapes, num_rows, num_heads, num_levels,
+                     num_points, m_live);
+  return simpb_check_launch();
+}

@@ -57,10 +57,12 @@ class DeformableFeatureAggregation(BaseModule):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.constant_(self.output_proj.bias, 0.0)
 
-    def forward(self, instance_feature, anchor, anchor_embed, feature_maps, metas, keep_parts=False, **kwargs):
+    def forward(self, instance_feature, anchor, anchor_embed, feature_maps, metas, keep_parts=False, cam_embed=None,
+                **kwargs):
         if (instance_feature.is_cuda and self.camera_encoder is not None and metas.get("image_wh") is not None
                 and getattr(self.kps_generator, "num_learnable_pts", 0) > 0):
-            return self._forward_fused(instance_feature, anchor, anchor_embed, feature_maps, metas, keep_parts)
+            return self._forward_fused(instance_feature, anchor, anchor_embed, feature_maps, metas, keep_parts,
+                                       cam_embed)
         bs, num_anchor = instance_feature.shape[:2]
         key_points = self.kps_generator(anchor, instance_feature)
         weights = self._get_weights(instance_feature, anchor_embed, metas)
@@ -79,7 +81,8 @@ class DeformableFeatureAggregation(BaseModule):
             output = torch.cat([output, instance_feature], dim=-1)
         return output
 
-    def _forward_fused(self, instance_feature, anchor, anchor_embed, feature_maps, metas, keep_parts=False):
+    def _forward_fused(self, instance_feature, anchor, anchor_embed, feature_maps, metas, keep_parts=False,
+                       cam_embed=None):
         """Same dataflow as forward(), with the operand producers as two HIP kernels writing the
         aggregation kernel's own layouts (csrc/dfa_prep.hip) instead of ~25 PyTorch kernels, and the
         three Linear layers in front of them (learnable_fc on the feature, weights_fc on feature +
@@ -94,7 +97,8 @@ class DeformableFeatureAggregation(BaseModule):
         anchor_c = anchor.contiguous().float()
         proj = metas["projection_mat"].contiguous().float()
         wh = metas["image_wh"].contiguous().float()
-        cam_embed = fused.chain_forward(self.camera_encoder, proj[:, :, :3].reshape(bs, self.num_cams, -1))
+        if cam_embed is None:  # the head hands in the embeddings of all its layers, computed in one launch
+            cam_embed = fused.chain_forward(self.camera_encoder, proj[:, :, :3].reshape(bs, self.num_cams, -1))
         # weights_fc(f + e) = [f | e] . [W | W]^T + b; weights_fc(f + e + c) = that + c . W^T (no second bias)
         if dense.ENABLED:
             learn, feat_logits, cam_logits = dense.gemm(

@@ -29,7 +29,8 @@ class _Job(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p * MAX_SEGS), ("ldx", ctypes.c_int * MAX_SEGS), ("kseg", ctypes.c_int * MAX_SEGS),
                 ("num_seg", ctypes.c_int), ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
                 ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p), ("m_live", ctypes.c_void_p),
-                ("ldw", ctypes.c_int), ("ldy", ctypes.c_int), ("relu", ctypes.c_int), ("reserved", ctypes.c_int)]
+                ("ldw", ctypes.c_int), ("ldy", ctypes.c_int), ("relu", ctypes.c_int), ("reserved", ctypes.c_int),
+                ("row_flag", ctypes.c_void_p), ("bias2", ctypes.c_void_p)]
 
 
 class _Args(ctypes.Structure):
@@ -91,13 +92,14 @@ def rows2d(t):
     return t, rows, ld
 
 
-def job(xs, w, bias=None, relu=False, out=None, m_live=None):
-    """One problem of a grouped launch: y = relu?([xs...] . w^T + bias). xs: tensor or list of tensors
-    sharing their leading dimensions; w [N, K] (a row slice of a larger matrix is fine); out: optional
-    destination [..., N] view (e.g. a column range of a wider buffer)."""
+def job(xs, w, bias=None, relu=False, out=None, m_live=None, row_flag=None, bias2=None):
+    """One problem of a grouped launch: y = relu?([xs...] . w^T + bias [+ bias2 on rows whose
+    row_flag != 0]). xs: tensor or list of tensors sharing their leading dimensions; w [N, K] (a row
+    slice of a larger matrix is fine); out: optional destination [..., N] view (e.g. a column range
+    of a wider buffer); row_flag i32 [rows], bias2 f32 [N]."""
     if torch.is_tensor(xs):
         xs = [xs]
-    return dict(xs=list(xs), w=w, bias=bias, relu=relu, out=out, m_live=m_live)
+    return dict(xs=list(xs), w=w, bias=bias, relu=relu, out=out, m_live=m_live, row_flag=row_flag, bias2=bias2)
 
 
 def gemm(*jobs):
@@ -150,15 +152,36 @@ def gemm(*jobs):
         jb.relu = 1 if spec["relu"] else 0
         ml = spec["m_live"]
         jb.m_live = ml.data_ptr() if ml is not None else None
-        keep += [w, bias, out, ml]
+        rf, b2 = spec.get("row_flag"), spec.get("bias2")
+        if (rf is None) != (b2 is None):
+            raise ValueError("row_flag and bias2 go together")
+        if rf is not None:
+            if rf.dtype != torch.int32 or not rf.is_contiguous() or rf.numel() != m or b2.numel() != n:
+                raise ValueError("row_flag must be contiguous i32 [rows], bias2 f32 [N]")
+            b2 = b2.float().contiguous()
+            jb.row_flag, jb.bias2 = rf.data_ptr(), b2.data_ptr()
+        keep += [w, bias, out, ml, rf, b2]
         outs.append(out)
     if any(o.numel() for o in outs):
         _lib.check(_lib.lib().simpb_gemm_f32(ctypes.byref(args), _stream()), "simpb_gemm_f32")
     return outs
 
 
-def linear(xs, w, bias=None, relu=False, out=None, m_live=None):
-    return gemm(job(xs, w, bias, relu, out, m_live))[0]
+def linear(xs, w, bias=None, relu=False, out=None, m_live=None, row_flag=None, bias2=None):
+    return gemm(job(xs, w, bias, relu, out, m_live, row_flag, bias2))[0]
+
+
+def rowdot_sigmoid(x, w, b, m_live=None):
+    """sigmoid(x . w + b) per row: x [..., k], w [1, k] or [k], b [1] -> [..., 1]."""
+    xt, rows, ld = rows2d(x)
+    out = torch.empty(x.shape[:-1] + (1,), device=x.device, dtype=torch.float32)
+    w = w.reshape(-1).float().contiguous()
+    if rows:
+        _lib.check(_lib.lib().simpb_rowdot_sigmoid(out.data_ptr(), xt.data_ptr(), ld, w.data_ptr(),
+                                                   b.data_ptr() if b is not None else None, rows, x.shape[-1],
+                                                   m_live.data_ptr() if m_live is not None else None, _stream()),
+                   "simpb_rowdot_sigmoid")
+    return out
 
 
 def layernorm(xs, ln, out=None, m_live=None):
@@ -258,6 +281,17 @@ def fold_ffn_out(fc2, identity_fc):
 
     return _folds.get(("ffn_out", id(fc2), id(identity_fc)),
                       (fc2.weight, fc2.bias, identity_fc.weight, identity_fc.bias), build)
+
+
+def fold_split_last_column(lin):
+    """A Linear over cat(x, flag) with a 0/1 flag column: (weight over x [N, K-1] with 16-byte aligned
+    rows, column of the flag [N])."""
+
+    def build():
+        w = lin.weight.detach().float()
+        return w[:, :-1].contiguous(), w[:, -1].contiguous()
+
+    return _folds.get(("split_last", id(lin)), (lin.weight,), build)
 
 
 def fold_sum_input(lin, copies=2):

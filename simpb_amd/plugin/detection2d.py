@@ -112,7 +112,11 @@ class SparseBox2DRefinementModule(BaseModule):
             ef, lde = fused._rows(anchor2d_embed, anchor2d_embed.shape[-1])
             n, lead = xf.shape[0], instance_feature.shape[:-1]
             out_t = torch.empty(n, self.output_dim, device=xf.device)
-            jobs = [dict(plan=fused.plan_of(self.layers), x=(xf, ldx, 0), x2=(ef, lde, 0), out=(out_t, self.output_dim, 0))]
+            # :122-125 + the final sigmoid (:144) as the chain's post stage
+            af, lda = fused._rows(anchor2d, anchor2d.shape[-1])
+            post = dict(kind=fused.POST_REFINE2D, res=(af, lda), res_cols=anchor2d.shape[-1])
+            jobs = [dict(plan=fused.plan_of(self.layers), x=(xf, ldx, 0), x2=(ef, lde, 0), out=(out_t, self.output_dim, 0),
+                         post=post)]
             cls_t = alpha_t = None
             if return_cls:
                 cls_t = torch.empty(n, self.num_cls, device=xf.device)
@@ -129,11 +133,11 @@ class SparseBox2DRefinementModule(BaseModule):
         k = anchor2d.shape[-1]
         if k not in (2, 4):
             raise ValueError(k)
-        output = torch.cat([output[..., :k] + inverse_sigmoid(anchor2d), output[..., k:]], dim=-1)  # :122-125
         if fused_ok:
             cls = cls_t.reshape(lead + (self.num_cls,)) if cls_t is not None else None
             alpha = alpha_t.reshape(lead + (alpha_t.shape[-1],)) if alpha_t is not None else None
-        else:
-            cls = self.cls_layers(instance_feature) if return_cls else None
-            alpha = self.alpha_layers(instance_feature) if self.with_alpha_branch else None
+            return output, cls, None, alpha
+        output = torch.cat([output[..., :k] + inverse_sigmoid(anchor2d), output[..., k:]], dim=-1)  # :122-125
+        cls = self.cls_layers(instance_feature) if return_cls else None
+        alpha = self.alpha_layers(instance_feature) if self.with_alpha_branch else None
         return output.sigmoid(), cls, None, alpha

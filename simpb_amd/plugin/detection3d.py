@@ -106,6 +106,38 @@ class SparseBox3DRefinementModule(BaseModule):
 
     def forward(self, instance_feature, anchor, anchor_embed, time_interval=1.0, return_cls=True):
         fused_ok = instance_feature.is_cuda
+        if fused_ok and not self.normalize_yaw and self.output_dim == 11 and anchor.shape[-1] == 11 and self.refine_yaw:
+            # the whole head in one launch: MLP, Scale, then :133-143 (anchor added on every state, the
+            # velocity columns divided by the time step first) as the chain's post stage
+            from . import fused
+            bs = instance_feature.shape[0]
+            if not isinstance(time_interval, torch.Tensor):
+                time_interval = instance_feature.new_tensor(time_interval)
+            ti = time_interval.to(torch.float32).reshape(-1)
+            ti = (ti.expand(bs) if ti.numel() == 1 else ti).contiguous()
+            af, lda = fused._rows(anchor, anchor.shape[-1])
+            post = dict(kind=fused.POST_REFINE3D, res=(af, lda), res_cols=11, div=ti,
+                        div_rows=instance_feature.shape[1], div_col0=VX)
+            xf, ldx = fused._rows(instance_feature, instance_feature.shape[-1])
+            ef, lde = fused._rows(anchor_embed, anchor_embed.shape[-1])
+            n, lead = xf.shape[0], instance_feature.shape[:-1]
+            out = torch.empty(n, self.output_dim, device=xf.device)
+            jobs = [dict(plan=fused.plan_of(self.layers), x=(xf, ldx, 0), x2=(ef, lde, 0), out=(out, self.output_dim, 0),
+                         post=post)]
+            cls = quality = None
+            if return_cls:
+                assert self.with_cls_branch, "Without classification layers !!!"
+                cls = torch.empty(n, self.num_cls, device=xf.device)  # cls_layers(feature), :145-147
+                jobs.append(dict(plan=fused.plan_of(self.cls_layers), x=(xf, ldx, 0), out=(cls, self.num_cls, 0)))
+                if self.with_quality_estimation:  # quality_layers(feature + embed), :149-152
+                    quality = torch.empty(n, 2, device=xf.device)
+                    jobs.append(dict(plan=fused.plan_of(self.quality_layers), x=(xf, ldx, 0), x2=(ef, lde, 0),
+                                     out=(quality, 2, 0)))
+                    quality = quality.reshape(lead + (2,))
+                cls = cls.reshape(lead + (self.num_cls,))
+            if n:
+                fused.run_chains(jobs, n, xf.device)
+            return out.reshape(lead + (self.output_dim,)), cls, quality
         if fused_ok:
             from . import fused
             output = fused.chain_forward(self.layers, instance_feature, anchor_embed)
@@ -197,6 +229,8 @@ class SparseBox3DKeyPointsGenerator(BaseModule):
     def anchor_projection(anchor, T_src2dst_list, src_timestamp=None, dst_timestamps=None, time_intervals=None):
         """detection3d/blocks.py:248-280 including its acknowledged quirk (:271-278): the yaw pair
         is rotated as [cos, sin] and written back in that order into the [sin, cos] slots."""
+        if anchor.is_cuda and anchor.dim() == 3 and anchor.shape[-1] == 11:
+            return _anchor_projection_hip(anchor, T_src2dst_list, src_timestamp, dst_timestamps, time_intervals)
         dst_anchors = []
         for i in range(len(T_src2dst_list)):
             vel = anchor[..., VX:]
@@ -221,6 +255,31 @@ class SparseBox3DKeyPointsGenerator(BaseModule):
     @staticmethod
     def distance(anchor):
         return torch.norm(anchor[..., :2], p=2, dim=-1)
+
+
+def _anchor_projection_hip(anchor, T_src2dst_list, src_timestamp, dst_timestamps, time_intervals):
+    """anchor_projection as one launch per transform (csrc/rowops.hip) instead of three batched 3x3
+    matmuls through the vendor GEMM (27-44 us each on 600 anchors) and ten elementwise kernels."""
+    from .. import _lib
+    from .ops import _ptr, _stream
+    bs, n, _ = anchor.shape
+    src = anchor.contiguous().float()
+    outs = []
+    for i, T in enumerate(T_src2dst_list):
+        if time_intervals is not None:
+            dt = time_intervals[i]
+        elif src_timestamp is not None and dst_timestamps is not None:
+            dt = src_timestamp - dst_timestamps[i]
+        else:
+            dt = None
+        if dt is not None:
+            dt = dt.to(device=src.device, dtype=torch.float32).reshape(bs).contiguous()
+        T = T.to(device=src.device, dtype=torch.float32).reshape(bs, 4, 4).contiguous()
+        out = torch.empty_like(src)
+        _lib.check(_lib.lib().simpb_anchor_projection(_ptr(out), _ptr(src), _ptr(T), _ptr(dt) if dt is not None else None,
+                                                      bs, n, _stream()), "simpb_anchor_projection")
+        outs.append(out)
+    return outs
 
 
 def bbox_cxcywh_to_xyxy(bbox):

@@ -11,7 +11,8 @@ from .. import _lib
 from .layers import Scale
 from .ops import _stream
 
-MAX_OPS, MAX_CHAINS = 12, 4
+MAX_OPS, MAX_CHAINS = 12, 8
+POST_NONE, POST_REFINE3D, POST_REFINE2D, POST_SIGMOID = 0, 1, 2, 3
 TRANSPOSED_WEIGHTS = False  # False: matrix-core kernel on the weights as stored; True: VALU kernel on transposed copies
 LINEAR, LAYERNORM = 0, 1
 IN_ROWS, IN_SINE2D = 0, 1
@@ -25,7 +26,10 @@ class _Op(ctypes.Structure):
 class _Chain(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("x2", ctypes.c_void_p), ("out", ctypes.c_void_p),
                 ("out_scale", ctypes.c_void_p), ("ldx", ctypes.c_int), ("ldx2", ctypes.c_int), ("ldo", ctypes.c_int),
-                ("in_dim", ctypes.c_int), ("in_mode", ctypes.c_int), ("n_ops", ctypes.c_int), ("ops", _Op * MAX_OPS)]
+                ("in_dim", ctypes.c_int), ("in_mode", ctypes.c_int), ("n_ops", ctypes.c_int),
+                ("post", ctypes.c_int), ("ldres", ctypes.c_int), ("res_cols", ctypes.c_int), ("div_rows", ctypes.c_int),
+                ("div_col0", ctypes.c_int), ("reserved", ctypes.c_int), ("res", ctypes.c_void_p), ("div", ctypes.c_void_p),
+                ("ops", _Op * MAX_OPS)]
 
 
 class _Args(ctypes.Structure):
@@ -119,9 +123,10 @@ def _rows(t, width):
 
 def run_chains(jobs, num_rows, device):
     """jobs: list of dicts(plan, x=(tensor2d, ld, col), x2=(tensor2d, ld, col) or None, out=(tensor2d, ld, col),
-    sine=bool). All tensors f32 on `device`, 2-D views with unit inner stride."""
+    sine=bool, post=dict(kind, res=(tensor2d, ld), res_cols, div=tensor or None, div_rows, div_col0) or None).
+    All tensors f32 on `device`, 2-D views with unit inner stride."""
     if not jobs or len(jobs) > MAX_CHAINS:
-        raise ValueError("1..4 chains per launch")
+        raise ValueError("1..8 chains per launch")
     args = _Args()
     args.num_rows, args.num_chains = int(num_rows), len(jobs)
     args.weights_transposed = 1 if TRANSPOSED_WEIGHTS else 0
@@ -141,17 +146,27 @@ def run_chains(jobs, num_rows, device):
         ch.out, ch.ldo = ot.data_ptr() + 4 * ocol, ldo
         ch.in_mode = IN_SINE2D if job.get("sine") else IN_ROWS
         ch.in_dim = plan.in_dim
+        post = job.get("post")
+        if post:
+            ch.post = post["kind"]
+            if post.get("res") is not None:
+                rt, ldres = post["res"]
+                ch.res, ch.ldres, ch.res_cols = rt.data_ptr(), ldres, post["res_cols"]
+                keep.append(rt)
+            if post.get("div") is not None:
+                ch.div, ch.div_rows, ch.div_col0 = post["div"].data_ptr(), post["div_rows"], post["div_col0"]
+                keep.append(post["div"])
         plan.fill(ch, keep)
         keep += [xt, ot]
     status = _lib.lib().simpb_mlp_chain_forward(ctypes.byref(args), _stream())
     _lib.check(status, "simpb_mlp_chain_forward")
 
 
-def chain_forward(seq, x, x2=None, sine=False):
-    """y = seq(x + x2) for x [..., in_dim] on the GPU, one launch."""
+def chain_forward(seq, x, x2=None, sine=False, post=None):
+    """y = post(seq(x + x2)) for x [..., in_dim] on the GPU, one launch."""
     plan = plan_of(seq)
     xf, ldx = _rows(x, x.shape[-1])
-    job = dict(plan=plan, x=(xf, ldx, 0), sine=sine)
+    job = dict(plan=plan, x=(xf, ldx, 0), sine=sine, post=post)
     if x2 is not None:
         x2f, ldx2 = _rows(x2, x2.shape[-1])
         job["x2"] = (x2f, ldx2, 0)

@@ -128,23 +128,37 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
             assert bcs // self.num_cams == bs
             value = self.project_value(value, key_padding_mask)
         value = value.reshape(bs, self.num_cams, num_value, self.num_heads, -1)
-        if fused:
-            # sampling_offsets(q + pos) and attention_weights(q + pos) as one product [q | pos] . [W | W]^T
-            w, b = dense.fold_stack("msda_in", [self.sampling_offsets, self.attention_weights], copies=2)
-            both = dense.linear([raw_query, query_pos], w, b, m_live=m_live)
-            n_off = self.sampling_offsets.out_features
-            sampling_offsets, attention_weights = both[..., :n_off], both[..., n_off:]
-        else:
-            sampling_offsets, attention_weights = self.sampling_offsets(query), self.attention_weights(query)
-        sampling_offsets = sampling_offsets.reshape(bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
-        attention_weights = attention_weights.reshape(
-            bs, num_query, self.num_heads, self.num_levels * self.num_points).softmax(-1)
-        attention_weights = attention_weights.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
         if reference_points.shape[-1] not in (2, 3):
             raise NotImplementedError("SimPB passes 2-d reference points (simpb_head.py:523)")
-        offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
-        sampling_locations = reference_points[:, :, None, :, None, :2] \
-            + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+        if fused:
+            # sampling_offsets(q + pos) and attention_weights(q + pos) as one product [q | pos] . [W | W]^T,
+            # then softmax + reference point + offset / (W_l, H_l) in one launch (csrc/rowops.hip)
+            from .. import _lib
+            from .ops import _ptr, _stream
+            w, b = dense.fold_stack("msda_in", [self.sampling_offsets, self.attention_weights], copies=2)
+            both = dense.linear([raw_query, query_pos], w, b, m_live=m_live)
+            ref, _, ldref = dense.rows2d(reference_points[..., :2])
+            lp = self.num_levels * self.num_points
+            sampling_locations = torch.empty(bs, num_query, self.num_heads, self.num_levels, self.num_points, 2,
+                                             device=query.device)
+            attention_weights = torch.empty(bs, num_query, self.num_heads, self.num_levels, self.num_points,
+                                            device=query.device)
+            shapes = spatial_shapes.contiguous().long()
+            if both.shape[-1] != 3 * self.num_heads * lp:
+                raise ValueError("sampling_offsets / attention_weights widths do not match heads x levels x points")
+            _lib.check(_lib.lib().simpb_msda_prep(
+                _ptr(sampling_locations), _ptr(attention_weights), _ptr(both), both.shape[-1], _ptr(ref), ldref,
+                _ptr(shapes), bs * num_query, self.num_heads, self.num_levels, self.num_points,
+                _ptr(m_live) if m_live is not None else None, _stream()), "simpb_msda_prep")
+        else:
+            sampling_offsets = self.sampling_offsets(query).view(
+                bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+            attention_weights = self.attention_weights(query).view(
+                bs, num_query, self.num_heads, self.num_levels * self.num_points).softmax(-1)
+            attention_weights = attention_weights.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
+            offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
         if kwargs.get("ref_depth2d") is not None:
             raise NotImplementedError("ref_depth2d masking is not used by SimPBHead")
         if kwargs.get("query_groups", None) is not None:

@@ -190,6 +190,28 @@ class SimPBHead(BaseModule):
         return self.fc_after2d(self.layers[index](query, key, value, query_pos=query_pos, key_pos=key_pos,
                                                   value_pre=pre, **kwargs))
 
+    def _camera_embeddings(self, metas, batch_size):
+        """camera_encoder of every deformable layer (blocks.py:93-99,174-176) in ONE chain launch at the
+        start of the frame: they depend on projection_mat and their own weights only, and each is a
+        6-row, latency-bound chain (22 us) that would otherwise sit on the critical path of its layer."""
+        proj = metas.get("projection_mat")
+        idx = [i for i, op in enumerate(self.operation_order)
+               if op == "deformable" and getattr(self.layers[i], "camera_encoder", None) is not None]
+        if proj is None or not proj.is_cuda or not idx or len(idx) > 8 or not dense.ENABLED:
+            return {}
+        from . import fused
+        cam_in = proj[:, :, :3].reshape(batch_size * self.num_cams, -1).float().contiguous()
+        jobs, outs = [], {}
+        for i in idx:
+            plan = fused.plan_of(self.layers[i].camera_encoder)
+            if plan.in_dim != cam_in.shape[1]:
+                return {}
+            out = torch.empty(cam_in.shape[0], plan.out_dim, device=cam_in.device)
+            jobs.append(dict(plan=plan, x=(cam_in, cam_in.shape[1], 0), out=(out, plan.out_dim, 0)))
+            outs[i] = out.reshape(batch_size, self.num_cams, plan.out_dim)
+        fused.run_chains(jobs, cam_in.shape[0], cam_in.device)
+        return outs
+
     def _next_is_ffn(self, i):
         """True when op i+1 is the FFN, whose pre-norm reads a residual_mode="cat" result as two
         segments in place (dense.Segments) instead of a materialised concatenation."""
@@ -207,8 +229,14 @@ class SimPBHead(BaseModule):
 
         instance_feature, anchor, temp_instance_feature, temp_anchor, time_interval = self.instance_bank.get(
             batch_size, metas, dn_metas=None)
-        anchor_embed = self.anchor_encoder(anchor)
-        temp_anchor_embed = self.anchor_encoder(temp_anchor) if temp_anchor is not None else None
+        if temp_anchor is not None and anchor.is_cuda:
+            # one encoder launch over both anchor sets (the chain kernel is latency-bound per launch)
+            both = self.anchor_encoder.forward(torch.cat([anchor, temp_anchor], dim=1))
+            anchor_embed = dense.report(self.anchor_encoder, both[:, : anchor.shape[1]])
+            temp_anchor_embed = dense.report(self.anchor_encoder, both[:, anchor.shape[1]:])
+        else:
+            anchor_embed = self.anchor_encoder(anchor)
+            temp_anchor_embed = self.anchor_encoder(temp_anchor) if temp_anchor is not None else None
 
         quality, prediction, classification = [], [], []
         prediction2d, classification2d, prediction_alpha2d, prediction_depth2d = [], [], [], []
@@ -218,6 +246,7 @@ class SimPBHead(BaseModule):
         temp_attn_instance = instance_feature
         pre_values = feature_maps[3] if len(feature_maps) > 3 else None
         encoder2d_dict, feature_maps = self.prepare2d(feature_maps, metas)
+        cam_embeds = self._camera_embeddings(metas, batch_size)
         alloc = None
         self._m_live = None
         last = len(self.operation_order) - 1
@@ -249,7 +278,7 @@ class SimPBHead(BaseModule):
                 instance_feature, anchor_embed, anchor = layer(
                     query2d=instance_feature, query_pos2d=anchor_embed2d, anchor2d=anchor2d,
                     query3d=temp_attn_instance, query_pos3d=anchor_embed, anchor3d=anchor,
-                    allocation=alloc, attn_mask=None, graph_model=self.graph_model)
+                    allocation=alloc, attn_mask=None, graph_model=self.graph_model, m_live=self._m_live)
                 self.instance_status = "3d"
                 self._m_live = None
             elif op == "qg_self_attn":
@@ -283,7 +312,8 @@ class SimPBHead(BaseModule):
                 temp_attn_instance = instance_feature
             elif op == "deformable":
                 instance_feature = layer(instance_feature, anchor, anchor_embed, feature_maps, metas,
-                                         keep_parts=dense.ENABLED and self._next_is_ffn(i))
+                                         keep_parts=dense.ENABLED and self._next_is_ffn(i),
+                                         cam_embed=cam_embeds.get(i))
             elif op == "refine3d":
                 anchor, cls, qt = layer(
                     instance_feature, anchor, anchor_embed, time_interval=time_interval,

@@ -215,3 +215,91 @@ def test_fused_ffn_matches_unfused_route():
         x = ffn.pre_norm(torch.cat([a, b], -1))
         want = ffn.identity_fc(x) + ffn.layers(x)
     assert float((got - want).abs().max()) <= 5e-5 * max(1.0, float(want.abs().max()))
+
+
+@gpu
+def test_gemm_flagged_extra_bias_is_the_257th_column():
+    """ReWeight.reduce over cat(q, is_center) (aggregation.py:19-21) as a 256-wide product + flagged bias."""
+    g = torch.Generator().manual_seed(21)
+    lin = nn.Linear(257, 256)
+    q = torch.randn(1, 700, 256, generator=g)
+    flag = (torch.rand(1, 700, generator=g) > 0.5).to(torch.int32)
+    want = F.relu(lin.double()(torch.cat([q, flag[..., None].float()], -1).double()))
+    lin = lin.float().cuda()
+    w_x, w_flag = dense.fold_split_last_column(lin)
+    got = dense.linear(q.cuda(), w_x, lin.bias, relu=True, row_flag=flag.cuda().reshape(-1), bias2=w_flag).cpu()
+    assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    alp = nn.Linear(256, 1)
+    want_a = torch.sigmoid(alp.double()(want))
+    live = torch.tensor([650], dtype=torch.int32, device="cuda")
+    got_a = dense.rowdot_sigmoid(got.cuda(), alp.float().cuda().weight, alp.bias, m_live=live).cpu()
+    assert got_a.shape == (1, 700, 1)
+    assert float((got_a[:, :650].double() - want_a[:, :650]).abs().max()) < 1e-5 and bool((got_a[:, 650:] == 0).all())
+
+
+@gpu
+def test_anchor_projection_kernel_vs_reference_formula():
+    """csrc/rowops.hip against the PyTorch statement of detection3d/blocks.py:248-280 (run on the CPU),
+    including the swapped yaw pair."""
+    from simpb_amd.plugin.detection3d import SparseBox3DKeyPointsGenerator as K
+    g = torch.Generator().manual_seed(22)
+    anchor = torch.randn(2, 600, 11, generator=g)
+    T = torch.eye(4).repeat(2, 1, 1)
+    ang = torch.tensor([0.3, -1.1])
+    T[:, 0, 0], T[:, 0, 1], T[:, 1, 0], T[:, 1, 1] = ang.cos(), -ang.sin(), ang.sin(), ang.cos()
+    T[:, :3, 3] = torch.randn(2, 3, generator=g)
+    dt = torch.tensor([0.5, -0.25])
+    for ti in (None, [-dt]):
+        want = K.anchor_projection(anchor, [T], time_intervals=ti)[0]
+        got = K.anchor_projection(anchor.cuda(), [T.cuda()], time_intervals=None if ti is None else [-dt.cuda()])[0].cpu()
+        assert float((got - want).abs().max()) < 1e-5
+
+
+@gpu
+def test_msda_prep_kernel_vs_torch_ops():
+    """group_attn.py:181-201: softmax over levels x points per head, location = ref + offset / (W, H)."""
+    g = torch.Generator().manual_seed(23)
+    bs, nq, heads, L, P = 1, 333, 8, 4, 4
+    raw = torch.randn(bs, nq, heads * L * P * 3, generator=g)
+    ref = torch.rand(bs, nq, 1, 2, generator=g)
+    shapes = torch.tensor([[64, 176], [32, 88], [16, 44], [8, 22]])
+    off = raw[..., : heads * L * P * 2].reshape(bs, nq, heads, L, P, 2)
+    want_w = raw[..., heads * L * P * 2:].reshape(bs, nq, heads, L * P).softmax(-1).reshape(bs, nq, heads, L, P)
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+    want_loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    from simpb_amd import _lib
+    loc = torch.empty(bs, nq, heads, L, P, 2, device="cuda")
+    att = torch.empty(bs, nq, heads, L, P, device="cuda")
+    live = torch.tensor([300], dtype=torch.int32, device="cuda")
+    rawc, refc, sh = raw.cuda(), ref.cuda().reshape(bs * nq, 2), shapes.cuda().long()
+    _lib.check(_lib.lib().simpb_msda_prep(loc.data_ptr(), att.data_ptr(), rawc.data_ptr(), raw.shape[-1], refc.data_ptr(), 2,
+                                          sh.data_ptr(), bs * nq, heads, L, P, live.data_ptr(), None), "simpb_msda_prep")
+    torch.cuda.synchronize()
+    assert float((loc.cpu()[:, :300] - want_loc[:, :300]).abs().max()) < 1e-6
+    assert float((att.cpu()[:, :300] - want_w[:, :300]).abs().max()) < 1e-6
+    assert bool((loc[:, 300:] == 0).all()) and bool((att[:, 300:] == 0).all())
+
+
+@gpu
+def test_chain_post_stages_match_the_module_formulas():
+    """The refinement heads with their post stage inside the chain launch (detection3d/blocks.py:133-143,
+    detection2d/blocks.py:122-125,144) against the same modules evaluated with plain PyTorch on the CPU."""
+    from simpb_amd.plugin.detection2d import SparseBox2DRefinementModule
+    from simpb_amd.plugin.detection3d import SparseBox3DRefinementModule
+    torch.manual_seed(24)
+    r3 = SparseBox3DRefinementModule(embed_dims=256, num_cls=10, refine_yaw=True, with_quality_estimation=True).eval()
+    f, e, a = torch.randn(2, 90, 256), torch.randn(2, 90, 256), torch.randn(2, 90, 11)
+    dt = torch.tensor([0.5, 0.4])
+    with torch.no_grad():
+        want = r3(f, a, e, time_interval=dt, return_cls=True)
+        got = r3.cuda()(f.cuda(), a.cuda(), e.cuda(), time_interval=dt.cuda(), return_cls=True)
+        for w, gt in zip(want, got):
+            assert float((gt.cpu() - w).abs().max()) <= 5e-5 * max(1.0, float(w.abs().max()))
+        r2 = SparseBox2DRefinementModule(embed_dims=256, num_cls=10, with_alpha_branch=True).eval()
+        a2 = torch.rand(2, 90, 2)
+        a2[0, 0] = torch.tensor([0.0, 1.0])   # the clamped ends of inverse_sigmoid
+        want = r2(f, a2, e)
+        got = r2.cuda()(f.cuda(), a2.cuda(), e.cuda())
+        for w, gt in zip(want, got):
+            if w is not None:
+                assert float((gt.cpu() - w).abs().max()) <= 5e-5 * max(1.0, float(w.abs().max()))
