@@ -12,9 +12,25 @@
 // wave-load per k, L2-resident and shared by all workgroups), the row tile is broadcast from LDS.
 // Up to 4 independent chains (e.g. the 4 encoder branches) share a launch through blockIdx.y.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/simpb_hip.h"
 
 extern "C" int simpb_check_launch(void);
+
+#ifdef SIMPB_CHAIN_STAMPS
+// diagnostic build only (tools/chain_stamps.py): s_memtime of workgroup (0, 0), wave 0 at phase boundaries
+__device__ unsigned long long g_chain_stamps[128];
+#define SIMPB_STAMP(i)                                                                       \
+  do {                                                                                       \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (i) < 128)                 \
+      g_chain_stamps[(i)] = __builtin_amdgcn_s_memtime();                                    \
+  } while (0)
+extern "C" int simpb_debug_chain_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_stamps), sizeof(g_chain_stamps));
+}
+#else
+#define SIMPB_STAMP(i) do {} while (0)
+#endif
 
 namespace {
 
@@ -229,12 +245,36 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_chain_kernel(simpb_mlp_args ar
 
 // ---- matrix-core variant: 16 rows per workgroup, 8 waves; wave w owns output columns [32w, 32w+32)
 // of a Linear layer as two 16x16 tiles of v_mfma_f32_16x16x4_f32 (exact fp32). Operands use the
-// ORIGINAL weight layout [out][in]: with the k-order permuted (lane quarter kq takes k = 16*kq + s
-// inside each 64-wide k-chunk) a lane's 16 operand values are contiguous both in the weight row it
-// reads from L2 and in the activation row it reads from LDS, so they arrive as float4 loads; A and
-// B use the same permutation, so the sum is unchanged.
+// ORIGINAL weight layout [out][in] with the k-order permuted inside each 64-wide k-chunk: load j of
+// lane quarter kq is the float4 at k = 16*j + 4*kq, so the four lanes of a weight row read 64
+// CONTIGUOUS bytes per instruction (16 half-lines per wave-load; with k = 16*kq + 4*j it was four
+// scattered 16-byte pieces per row = 32 lines per wave-load). A and B use the same permutation, so
+// the sum is unchanged.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kMR = 16, kMW = 8;
+
+// compile-time loop (register-set indices must be constants in the front end: csrc/gemm.hip)
+template <int D, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (D < N) {
+    f(std::integral_constant<int, D>{});
+    static_for<D + 1, N>(f);
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true);
+  return x + __builtin_bit_cast(float, y);
+}
+// sum over the 32 lanes of a half wave (lanes 0-31 / 32-63), result in every lane of the half
+__device__ __forceinline__ float half_wave_sum(float x) {
+  x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]: lane ^ 1
+  x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]: lane ^ 2
+  x = dpp_add<0x141>(x);   // row_half_mirror: i <-> 7 - i inside 8 lanes (every quad already holds its sum)
+  x = dpp_add<0x140>(x);   // row_mirror: i <-> 15 - i inside the 16-lane row
+  return x + __shfl_xor(x, 16);
+}
 
 __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args args) {
   constexpr int kThreads = kMW * 64;
@@ -244,6 +284,7 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
   const int lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * kMR;
   const int N = args.num_rows;
+  SIMPB_STAMP(0);
 
   if (ch.in_mode == SIMPB_MLP_IN_SINE2D) {
     for (int idx = tid; idx < kMR * 256; idx += kThreads) {
@@ -259,6 +300,24 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
       }
       act[0][r][j] = v;
     }
+  } else if ((ch.in_dim & (ch.in_dim - 1)) == 0 && ch.in_dim >= 4 && (ch.ldx & 3) == 0 && (ch.ldx2 & 3) == 0 &&
+             ((reinterpret_cast<size_t>(ch.x) | reinterpret_cast<size_t>(ch.x2)) & 15) == 0) {
+    // power-of-two width: 16-byte loads, shifts instead of divisions, every load of the tile in flight at once
+    const int q = ch.in_dim >> 2, sh = __ffs(q) - 1;
+#pragma unroll 2
+    for (int idx = tid; idx < kMR * q; idx += kThreads) {
+      const int r = idx >> sh, c4 = idx & (q - 1);
+      const int row = row0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < N) {
+        v = *reinterpret_cast<const float4*>(ch.x + (size_t)row * ch.ldx + 4 * c4);
+        if (ch.x2) {
+          const float4 u = *reinterpret_cast<const float4*>(ch.x2 + (size_t)row * ch.ldx2 + 4 * c4);
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+      }
+      *reinterpret_cast<float4*>(&act[0][r][4 * c4]) = v;
+    }
   } else {
     for (int idx = tid; idx < kMR * ch.in_dim; idx += kThreads) {
       const int r = idx / ch.in_dim, k = idx - r * ch.in_dim;
@@ -273,10 +332,12 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
   }
   __syncthreads();
 
+  SIMPB_STAMP(1);
   int cur = 0;
   int width = ch.in_mode == SIMPB_MLP_IN_SINE2D ? 256 : ch.in_dim;
   for (int o = 0; o < ch.n_ops; ++o) {
     const simpb_mlp_op& op = ch.ops[o];
+    SIMPB_STAMP(2 + 4 * o);
     if (op.type == SIMPB_MLP_LINEAR) {
       const int K = op.in_dim, D = op.out_dim;
       if ((K & 63) == 0) {  // any D: columns past D are fed zeros and not stored (D = 2..11 heads use wave 0 only)
@@ -285,42 +346,56 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
           const int r16 = lane & 15, kq = lane >> 4;
           const bool cv0 = col0 + r16 < D, cv1 = col0 + 16 + r16 < D;
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-          const float* w0 = op.w + (size_t)(cv0 ? col0 + r16 : 0) * K + 16 * kq;        // original layout [D][K]
-          const float* w1 = op.w + (size_t)(cv1 ? col0 + 16 + r16 : 0) * K + 16 * kq;
+          const float* w0 = op.w + (size_t)(cv0 ? col0 + r16 : 0) * K + 4 * kq;         // original layout [D][K]
+          const float* w1 = op.w + (size_t)(cv1 ? col0 + 16 + r16 : 0) * K + 4 * kq;
           const float m0 = cv0 ? 1.f : 0.f, m1 = cv1 ? 1.f : 0.f;
-          const float* ar = &act[cur][r16][16 * kq];
-          float4 b0[4], b1[4], nb0[4], nb1[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { b0[j] = *reinterpret_cast<const float4*>(w0 + 4 * j); b1[j] = *reinterpret_cast<const float4*>(w1 + 4 * j); }
-          for (int k0 = 0; k0 < K; k0 += 64) {
-            const bool more = k0 + 64 < K;
-            if (more) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                nb0[j] = *reinterpret_cast<const float4*>(w0 + k0 + 64 + 4 * j);
-                nb1[j] = *reinterpret_cast<const float4*>(w1 + k0 + 64 + 4 * j);
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float4 a = *reinterpret_cast<const float4*>(ar + k0 + 4 * j);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[j].x * m0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[j].x * m1, acc1, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[j].y * m0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[j].y * m1, acc1, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[j].z * m0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[j].z * m1, acc1, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[j].w * m0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[j].w * m1, acc1, 0, 0, 0);
-            }
-            if (more) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) { b0[j] = nb0[j]; b1[j] = nb1[j]; }
-            }
-          }
-          // C/D of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
+          const float* ar = &act[cur][r16][4 * kq];
           const int c0 = col0 + r16, c1 = col0 + 16 + r16;
-          const float bias0 = (op.b && cv0) ? op.b[c0] : 0.f, bias1 = (op.b && cv1) ? op.b[c1] : 0.f;
+          const float bias0 = (op.b && cv0) ? op.b[c0] : 0.f, bias1 = (op.b && cv1) ? op.b[c1] : 0.f;  // in flight with the weights
+          // Two register sets of weights (one 64-wide k-chunk each) ahead of the matrix work. Every
+          // request is UNCONDITIONAL (chunk index clamped; a layer narrower than 256 re-requests its last
+          // chunk) and the four chunk steps are unrolled at compile time, so the compiler can count the
+          // loads in flight and wait for the older set only. (Requesting the whole layer in one burst of
+          // four sets was measured too: no faster -- the CU's 64 B/clk load path serialises the eight
+          // waves' bursts, 256 KB = 4k cycles per layer, and the last wave starts late.) Measured before (s_memtime stamps,
+          // tools/chain_stamps.py): with the next chunk requested behind `if (more)` it waited for
+          // everything in front of the matrix instructions, each chunk paid a full round trip (~2.7k
+          // cycles) on top of its ~2k cycles of matrix work, and a 256x256 layer took ~23k cycles.
+          const int nchunk = K >> 6;
+          f32x4 wa[2][4], wb[2][4];
+          auto fetch = [&](auto set_c, int chunk) __attribute__((always_inline)) {
+            constexpr int set = decltype(set_c)::value;
+            const int kc = (chunk < nchunk ? chunk : nchunk - 1) * 64;
+            static_for<0, 4>([&](auto j) __attribute__((always_inline)) {
+              constexpr int jj = decltype(j)::value;
+              wa[set][jj] = *reinterpret_cast<const f32x4*>(w0 + kc + 16 * jj);
+              wb[set][jj] = *reinterpret_cast<const f32x4*>(w1 + kc + 16 * jj);
+            });
+          };
+          fetch(std::integral_constant<int, 0>{}, 0);
+          fetch(std::integral_constant<int, 1>{}, 1);
+          SIMPB_STAMP(3 + 4 * o);
+          static_for<0, 4>([&](auto c_c) __attribute__((always_inline)) {
+            constexpr int c = decltype(c_c)::value;
+            constexpr int set = c & 1;
+            if (c < nchunk) {
+              static_for<0, 4>([&](auto j) __attribute__((always_inline)) {
+                constexpr int jj = decltype(j)::value;
+                const float4 a = *reinterpret_cast<const float4*>(ar + c * 64 + 16 * jj);
+                const f32x4 b0 = wa[set][jj], b1 = wb[set][jj];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[0] * m0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[0] * m1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[1] * m0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[1] * m1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[2] * m0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[2] * m1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[3] * m0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[3] * m1, acc1, 0, 0, 0);
+              });
+            }
+            if constexpr (c + 2 < 4) fetch(std::integral_constant<int, set>{}, c + 2);
+          });
+          // C/D of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
@@ -342,42 +417,51 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
 #pragma unroll
         for (int r = 0; r < kMR; ++r) act[cur ^ 1][r][tid] = op.relu ? fmaxf(acc[r], 0.f) : acc[r];
       }
+      SIMPB_STAMP(4 + 4 * o);
       __syncthreads();
+      SIMPB_STAMP(5 + 4 * o);
       cur ^= 1;
       width = D;
     } else {
+      // LayerNorm of all 16 rows at once: 32 lanes per row, 8 elements per lane; the 32-lane sums
+      // are four DPP steps (quad xor 1, xor 2, half-row mirror, row mirror: register moves, no LDS
+      // crossbar) plus one ds_bpermute for the two 16-lane rows of the half wave. (One wave per row
+      // with six __shfl_xor steps per sum, two rows in sequence, was ~1.5 us of dependent
+      // ds_bpermute latency per LayerNorm, as much as the matrix work of a 128-wide layer.)
       const int D = op.in_dim;
-      for (int r = wave; r < kMR; r += kMW) {
-        float v[kMaxDim / 64];
-        float s = 0.f;
+      const int r = tid >> 5, l32 = tid & 31;
+      float g[kMaxDim / 32], be[kMaxDim / 32], v[kMaxDim / 32];
+      float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < kMaxDim / 64; ++j) {
-          const int e = lane + 64 * j;
-          v[j] = e < D ? act[cur][r][e] : 0.f;
-          s += v[j];
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        const float mean = s / (float)D;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < kMaxDim / 64; ++j) {
-          const int e = lane + 64 * j;
-          const float d = e < D ? v[j] - mean : 0.f;
-          q += d * d;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
-        const float inv = 1.f / sqrtf(q / (float)D + 1e-5f);
-#pragma unroll
-        for (int j = 0; j < kMaxDim / 64; ++j) {
-          const int e = lane + 64 * j;
-          if (e < D) act[cur][r][e] = (v[j] - mean) * inv * op.w[e] + op.b[e];
-        }
+      for (int j = 0; j < kMaxDim / 32; ++j) {
+        const int e = l32 + 32 * j;
+        const bool in = e < D;
+        g[j] = in ? op.w[e] : 0.f;   // requested before the reductions need them
+        be[j] = in ? op.b[e] : 0.f;
+        v[j] = in ? act[cur][r][e] : 0.f;
+        sum += v[j];
       }
+      sum = half_wave_sum(sum);
+      const float mean = sum / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < kMaxDim / 32; ++j) {
+        const float d = (l32 + 32 * j) < D ? v[j] - mean : 0.f;
+        q += d * d;
+      }
+      q = half_wave_sum(q);
+      const float inv = 1.f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+      for (int j = 0; j < kMaxDim / 32; ++j) {
+        const int e = l32 + 32 * j;
+        if (e < D) act[cur][r][e] = (v[j] - mean) * inv * g[j] + be[j];
+      }
+      SIMPB_STAMP(4 + 4 * o);
       __syncthreads();
+      SIMPB_STAMP(5 + 4 * o);
     }
   }
+  SIMPB_STAMP(126);
   for (int idx = tid; idx < kMR * width; idx += kThreads) {
     const int r = idx / width, t = idx - r * width;
     const int row = row0 + r;
@@ -388,6 +472,7 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
       ch.out[(size_t)row * ch.ldo + t] = v;
     }
   }
+  SIMPB_STAMP(127);
 }
 
 }  // namespace
