@@ -86,14 +86,14 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
   // V values are requested before the matrix work that does not need them, so their latency hides
   // behind the S^T product and the softmax (nothing else overlaps it at 2 waves per SIMD).
   auto load_k = [&](int kt, float (&kreg)[32]) {
+    // rows past the range read the first key of the range instead (finite values): their scores are
+    // masked to -inf below, so no select touches the loaded registers before the product needs them
     const int kk = kt + qi;
-    const bool k_ok = kk < ke;
-    const float* kp = kbase + (size_t)(k_ok ? kk : kb) * ldk + 32 * half;
+    const float* kp = kbase + (size_t)(kk < ke ? kk : kb) * ldk + 32 * half;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float4 t = *reinterpret_cast<const float4*>(kp + 4 * j);
-      kreg[4 * j + 0] = k_ok ? t.x : 0.f; kreg[4 * j + 1] = k_ok ? t.y : 0.f;
-      kreg[4 * j + 2] = k_ok ? t.z : 0.f; kreg[4 * j + 3] = k_ok ? t.w : 0.f;
+      kreg[4 * j + 0] = t.x; kreg[4 * j + 1] = t.y; kreg[4 * j + 2] = t.z; kreg[4 * j + 3] = t.w;
     }
   };
   float kcur[32], knext[32];
@@ -105,13 +105,16 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int kidx = kt + acc_row(s, half);
-      const bool k_ok = kidx < ke;
-      const float* vp = vbase + (size_t)(k_ok ? kidx : kb) * ldv + qi;
-      va0[s] = k_ok ? vp[0] : 0.f;
-      va1[s] = k_ok ? vp[32] : 0.f;
+      const float* vp = vbase + (size_t)(kidx < ke ? kidx : kb) * ldv + qi;  // past the range: weight 0 below
+      va0[s] = vp[0];
+      va1[s] = vp[32];
     }
+    // requested UNCONDITIONALLY (past the last tile load_k clamps every row to the first key of the
+    // range and the values are never used): a load behind `if (ktn < ke)` made the compiler wait for
+    // every outstanding load -- these and the V values above -- in front of the S^T product
     const int ktn = kt + 32 * kWaves;
-    if (ktn < ke) load_k(ktn, knext);
+    load_k(ktn, knext);
+    __builtin_amdgcn_sched_barrier(0);  // the requests stay here, ahead of the matrix work (the scheduler sank them)
     // ---- S^T tile = K_tile . Q^T  (A: lane (key, half) holds K[key][32*half + s])
     f32x16 st;
 #pragma unroll
@@ -148,10 +151,8 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0[s], st[s], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1[s], st[s], o1, 0, 0, 0);
     }
-    if (ktn < ke) {
 #pragma unroll
-      for (int s = 0; s < 32; ++s) kcur[s] = knext[s];
-    }
+    for (int s = 0; s < 32; ++s) kcur[s] = knext[s];
   }
 
   // ---- merge the 4 waves
