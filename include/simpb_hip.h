@@ -224,6 +224,12 @@ typedef struct simpb_mlp_args {
 } simpb_mlp_args;
 int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream);
 
+/* Top-k of each score row, sorted descending (ties: lower index first): values f32 [bs, k], indices
+ * i32 [bs, k] from scores f32 [bs, n], n <= 2048, k <= n. What `topk` of models/instance_bank.py:13-20
+ * and the ranking of SparseBox3DDecoder.decode (models/detection3d/decoder.py:145-167) ask of torch.topk /
+ * torch.sort; one launch, one workgroup per row. */
+int simpb_topk_rows(float* values, int* indices, const float* scores, int batch_size, int n, int k, void* stream);
+
 /* out[row] = sigmoid(dot(x[row, 0:k], w) + b[0]) : ReWeight.alpha (models/aggregation.py:23-24:
  * Linear(f_dim, 1) + Sigmoid) over rows of stride ldx. Rows >= *m_live (may be NULL) get 0. k % 4 == 0. */
 int simpb_rowdot_sigmoid(float* out, const float* x, int ldx, const float* w, const float* b, int num_rows, int k,

@@ -38,7 +38,7 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;  // native vector: plain loads/stores, no struct memcpy
 
-constexpr int BM = 32, BK = 64, LDK = BK + 4;
+constexpr int BM = 32, BK = 64;  // BK: granularity the host checks; kernels use BKT = 64 or 128
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 
@@ -59,16 +59,18 @@ struct GemmLaunch {
   int per_xcd;  // tiles per XCD range
 };
 
-template <int BN, int DEPTH>
+template <int BN, int DEPTH, int BKT>
 __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
   static_assert(DEPTH % 2 == 0, "LDS buffer index = register set index & 1");
+  constexpr int LDK = BKT + 4;            // LDS row stride: 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots
+  constexpr int C4 = BKT / 4;             // 16-byte columns of a chunk row
   constexpr int WN = BN / 32;             // waves across N
   constexpr int WK = kWaves / WN;         // waves across K
-  constexpr int KW = BK / WK;             // k values of a chunk per wave
+  constexpr int KW = BKT / WK;            // k values of a chunk per wave
   constexpr int KH = KW / 2;              // ... per lane half
-  constexpr int NX4 = BM * 16 / kThreads; // 16-byte X loads per thread per chunk
-  constexpr int NW4 = BN * 16 / kThreads; // 16-byte W loads per thread per chunk
-  constexpr int RS = kThreads / 16;       // rows covered by one pass of the staging threads
+  constexpr int NX4 = BM * C4 / kThreads; // 16-byte X loads per thread per chunk
+  constexpr int NW4 = BN * C4 / kThreads; // 16-byte W loads per thread per chunk
+  constexpr int RS = kThreads / C4;       // rows covered by one pass of the staging threads
   constexpr int LDP = BN + 1;
   constexpr int kStage = 2 * (BM + BN) * LDK;
   constexpr int kPart = WK * BM * LDP;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
   // every outstanding load (vmcnt(0)) instead of the oldest register set only. Addresses are a
   // wave-uniform base (segment pointer + k offset, scalar registers) plus a per-thread 32-bit offset
   // that does not change along K.
-  const int sr = tid >> 4, sc4 = tid & 15;
+  const int sr = tid / C4, sc4 = tid % C4;
   f32x4 px[DEPTH][NX4], pw[DEPTH][NW4];
   const float* __restrict__ w = job.w;
   unsigned xrow[NX4], wofs[NW4];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
   for (int i = 0; i < NX4; ++i) xrow[i] = (unsigned)min(row0 + sr + RS * i, live - 1);
 #pragma unroll
   for (int i = 0; i < NW4; ++i) wofs[i] = (unsigned)min(col0 + sr + RS * i, N - 1) * (unsigned)job.ldw + sc4 * 4;
-  const int nchunks = K / BK;
+  const int nchunks = K / BKT;
   const float* const x0 = job.x[0];
   const float* const x1 = job.x[1];
   const float* const x2 = job.x[2];
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
 
   auto fetch = [&](auto set_c, int chunk) __attribute__((always_inline)) {
     constexpr int set = decltype(set_c)::value;
-    const int k0 = min(chunk, nchunks - 1) * BK;
+    const int k0 = min(chunk, nchunks - 1) * BKT;
     // segment of this chunk (scalar selects; segment widths are multiples of the chunk)
     const float* xs = x0 + k0;
     unsigned ldx = l0;
@@ -285,6 +287,7 @@ extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
   L.a = *args;
   // tile width: 64 columns once that still fills the chip, 32 otherwise
   long long tiles64 = 0;
+  bool wide_k = true;  // every segment a multiple of 128 and K >= 512
   for (int j = 0; j < args->num_jobs; ++j) {
     const simpb_gemm_job& job = args->job[j];
     if (!job.y || !job.w || job.M <= 0 || job.N <= 0 || job.K <= 0 || job.K % BK) return SIMPB_EINVAL;
@@ -297,7 +300,9 @@ extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
           (reinterpret_cast<size_t>(job.x[s]) & 15))
         return SIMPB_EINVAL;
       ksum += job.kseg[s];
+      if (job.kseg[s] % 128) wide_k = false;
     }
+    if (job.K < 512) wide_k = false;
     if (ksum != job.K) return SIMPB_EINVAL;
     tiles64 += (long long)((job.M + BM - 1) / BM) * ((job.N + 63) / 64);
   }
@@ -314,9 +319,11 @@ extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
   dim3 grid(L.per_xcd * 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (bn == 64)
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 4>), grid, dim3(kThreads), 0, s, L);
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 4, 64>), grid, dim3(kThreads), 0, s, L);
+  else if (wide_k)  // 32-wide tiles: 128-deep chunks halve the barriers per matrix instruction (LDS 66 KB, 2 workgroups per CU)
+    hipLaunchKernelGGL((gemm_f32_kernel<32, 2, 128>), grid, dim3(kThreads), 0, s, L);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<32, 4>), grid, dim3(kThreads), 0, s, L);
+    hipLaunchKernelGGL((gemm_f32_kernel<32, 4, 64>), grid, dim3(kThreads), 0, s, L);
   return simpb_check_launch();
 }
 

@@ -103,7 +103,61 @@ __global__ __launch_bounds__(256) void rowdot_sigmoid_kernel(float* __restrict__
   if (lane == 0) out[row] = 1.f / (1.f + expf(-(s + (b ? b[0] : 0.f))));
 }
 
+// ---- top-k of one score row per workgroup (n <= 2048), sorted descending, ties by ascending index:
+// the whole row is bitonic-sorted in LDS as 64-bit keys (order-preserving bits of the float << 32 |
+// ~index). Replaces torch.topk(sorted=True) (a radix-select + a radix sort launch, 40-45 us on 900
+// scores) behind InstanceBank.update / cache / update_instance_id (instance_bank.py:13-20,137,159,191)
+// and SparseBox3DDecoder (decoder.py:145-167).
+template <int CAP>
+__global__ __launch_bounds__(CAP / 2) void topk_rows_kernel(float* __restrict__ val_out, int* __restrict__ idx_out,
+                                                          const float* __restrict__ scores, int n, int k) {
+  __shared__ unsigned long long key[CAP];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* row = scores + (size_t)b * n;
+  for (int i = tid; i < CAP; i += CAP / 2) {
+    unsigned long long kv = 0ull;  // padding sorts last
+    if (i < n) {
+      unsigned u = __float_as_uint(row[i]);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map float -> uint
+      kv = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+    }
+    key[i] = kv;
+  }
+  __syncthreads();
+  for (int size = 2; size <= CAP; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int lo = 2 * tid - (tid & (stride - 1));  // index of the lower element of this thread's pair
+      const int hi = lo + stride;
+      const bool desc = (lo & size) == 0;             // first half of each 2*size block descending
+      const unsigned long long a = key[lo], c = key[hi];
+      if ((a < c) == desc) { key[lo] = c; key[hi] = a; }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += CAP / 2) {
+    const unsigned long long kv = key[i];
+    unsigned u = (unsigned)(kv >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    val_out[(size_t)b * k + i] = __uint_as_float(u);
+    idx_out[(size_t)b * k + i] = (int)(0xFFFFFFFFu - (unsigned)(kv & 0xFFFFFFFFull));
+  }
+}
+
 }  // namespace
+
+extern "C" int simpb_topk_rows(float* values, int* indices, const float* scores, int batch_size, int n, int k,
+                               void* stream) {
+  if (!values || !indices || !scores || batch_size <= 0 || n <= 0 || k <= 0 || k > n || n > 2048) return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n <= 512)
+    hipLaunchKernelGGL(topk_rows_kernel<512>, dim3(batch_size), dim3(256), 0, s, values, indices, scores, n, k);
+  else if (n <= 1024)
+    hipLaunchKernelGGL(topk_rows_kernel<1024>, dim3(batch_size), dim3(512), 0, s, values, indices, scores, n, k);
+  else
+    hipLaunchKernelGGL(topk_rows_kernel<2048>, dim3(batch_size), dim3(1024), 0, s, values, indices, scores, n, k);
+  return simpb_check_launch();
+}
 
 extern "C" int simpb_rowdot_sigmoid(float* out, const float* x, int ldx, const float* w, const float* b, int num_rows,
                                     int k, const int* m_live, void* stream) {

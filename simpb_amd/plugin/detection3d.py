@@ -319,7 +319,13 @@ class SparseBox3DDecoder(object):
             cls_scores, cls_ids = cls_scores.max(dim=-1)
             cls_scores = cls_scores.unsqueeze(dim=-1)
         bs, num_pred, num_cls = cls_scores.shape
-        cls_scores, indices = cls_scores.flatten(start_dim=1).topk(self.num_output, dim=1, sorted=self.sorted)
+        flat = cls_scores.flatten(start_dim=1)
+        on_gpu = flat.is_cuda and flat.shape[1] <= 2048 and self.sorted
+        if on_gpu:  # one bitonic row sort (csrc/rowops.hip) instead of radix-select + radix-sort
+            from .ops import topk_rows
+            cls_scores, indices = topk_rows(flat, self.num_output)
+        else:
+            cls_scores, indices = flat.topk(self.num_output, dim=1, sorted=self.sorted)
         if not squeeze_cls:
             cls_ids = indices % num_cls
         mask = cls_scores >= self.score_threshold if self.score_threshold is not None else None
@@ -328,7 +334,10 @@ class SparseBox3DDecoder(object):
             centerness = torch.gather(qulity[output_idx][..., CNS], 1, indices // num_cls)
             cls_scores_origin = cls_scores.clone()
             cls_scores = cls_scores * centerness.sigmoid()
-            cls_scores, idx = torch.sort(cls_scores, dim=1, descending=True)
+            if on_gpu:
+                cls_scores, idx = topk_rows(cls_scores, cls_scores.shape[1])
+            else:
+                cls_scores, idx = torch.sort(cls_scores, dim=1, descending=True)
             if not squeeze_cls:
                 cls_ids = torch.gather(cls_ids, 1, idx)
             if mask is not None:

@@ -17,9 +17,19 @@ _STATE_FIELDS = ("cached_feature", "cached_anchor", "confidence", "instance_id",
 
 def topk(confidence, k, *inputs):
     """Rows of every input at the k largest confidences per batch row (instance_bank.py:13-20)."""
-    values, index = torch.topk(confidence, k, dim=1)
+    values, index = _rank(confidence, k)
     picked = [torch.gather(t, 1, index[..., None].expand(-1, -1, t.shape[-1])) for t in inputs]
     return values, picked
+
+
+def _rank(confidence, k):
+    """(values, indices) of the k largest entries per row, sorted descending. On the GPU one launch of
+    the bitonic row sort (csrc/rowops.hip; ties towards the lower index) instead of torch.topk's
+    radix-select + radix-sort pair."""
+    if confidence.is_cuda and confidence.dim() == 2 and confidence.shape[1] <= 2048:
+        from .ops import topk_rows
+        return topk_rows(confidence, k)
+    return torch.topk(confidence, k, dim=1)
 
 
 @PLUGIN_LAYERS.register_module()
@@ -63,7 +73,7 @@ class InstanceBank(nn.Module):
         for name in _STATE_FIELDS:
             setattr(self, name, None)
         self.prev_id = 0
-        self.metas = self.mask = self.temp_confidence = None
+        self.metas = self.mask = self.temp_confidence = self._kept_index = None
         self.has_history = False
         if self._static is not None:
             self._static["instance_id"].fill_(-1)
@@ -168,8 +178,10 @@ class InstanceBank(nn.Module):
             t = self.num_temp_instances
             score[:, :t] = torch.maximum(self.confidence * self.confidence_decay, score[:, :t])
         self.temp_confidence = score
-        kept_score, (kept_feature, kept_anchor) = topk(score, self.num_temp_instances, instance_feature.detach(),
-                                                       anchor.detach())
+        kept_score, index = _rank(score, self.num_temp_instances)
+        self._kept_index = index  # the same ranking decides which track ids survive (update_instance_id)
+        pick = lambda t: torch.gather(t, 1, index[..., None].expand(-1, -1, t.shape[-1]))  # noqa: E731
+        kept_feature, kept_anchor = pick(instance_feature.detach()), pick(anchor.detach())
         self._keep("confidence", kept_score)
         self._keep("cached_feature", kept_feature)
         self._keep("cached_anchor", kept_anchor)
@@ -194,9 +206,13 @@ class InstanceBank(nn.Module):
 
     def update_instance_id(self, instance_id=None, confidence=None):
         """Ids of the instances that cache() kept, padded with -1 (instance_bank.py:186-196)."""
-        if self.temp_confidence is not None:
-            rank_by = self.temp_confidence
+        if self.temp_confidence is not None and getattr(self, "_kept_index", None) is not None \
+                and self._kept_index.shape[0] == instance_id.shape[0]:
+            kept = torch.gather(instance_id, 1, self._kept_index)  # cache() ranked temp_confidence already
         else:
-            rank_by = confidence.max(dim=-1).values if confidence.dim() == 3 else confidence
-        kept = topk(rank_by, self.num_temp_instances, instance_id[..., None])[1][0].squeeze(dim=-1)
+            if self.temp_confidence is not None:
+                rank_by = self.temp_confidence
+            else:
+                rank_by = confidence.max(dim=-1).values if confidence.dim() == 3 else confidence
+            kept = topk(rank_by, self.num_temp_instances, instance_id[..., None])[1][0].squeeze(dim=-1)
         self._keep("instance_id", F.pad(kept, (0, self.num_anchor - self.num_temp_instances), value=-1))

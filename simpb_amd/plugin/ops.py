@@ -328,3 +328,19 @@ def bias_act_(y, bias, residual=None, relu=True):
                                                 n * h * w, c, 1 if relu else 0, _stream())
     _lib.check(status, "simpb_bias_act_nhwc_f16")
     return y
+
+
+def topk_rows(scores, k):
+    """(values [bs, k] sorted descending, indices i64 [bs, k]) of scores f32 [bs, n]: torch.topk(sorted=True)
+    semantics with ties broken towards the lower index, one launch (csrc/rowops.hip)."""
+    _require_gpu(scores)
+    if scores.dim() != 2 or scores.shape[1] > 2048:
+        raise ValueError("topk_rows takes [bs, n <= 2048] scores")
+    scores = scores.contiguous().float()
+    bs, n = scores.shape
+    values = torch.empty(bs, k, device=scores.device, dtype=torch.float32)
+    index = torch.empty(bs, k, device=scores.device, dtype=torch.int32)
+    if bs and k:
+        _lib.check(_lib.lib().simpb_topk_rows(_ptr(values), _ptr(index), _ptr(scores), bs, n, k, _stream()),
+                   "simpb_topk_rows")
+    return values, index.long()

@@ -303,3 +303,26 @@ def test_chain_post_stages_match_the_module_formulas():
         for w, gt in zip(want, got):
             if w is not None:
                 assert float((gt.cpu() - w).abs().max()) <= 5e-5 * max(1.0, float(w.abs().max()))
+
+
+@gpu
+@pytest.mark.parametrize("bs,n,k", [(1, 900, 600), (2, 900, 300), (1, 300, 300), (3, 37, 5), (1, 2048, 1)])
+def test_topk_rows_vs_torch_topk(bs, n, k):
+    """Bit-exact values, indices pointing at them, descending order, ties towards the lower index."""
+    from simpb_amd.plugin.ops import topk_rows
+    g = torch.Generator().manual_seed(n + k)
+    x = torch.randn(bs, n, generator=g)
+    x[0, : min(n, 8)] = 0.5          # ties
+    if n > 20:
+        x[0, 17] = float("-inf")
+        x[0, 3] = -0.0
+    want_v, _ = torch.topk(x, k, dim=1)
+    got_v, got_i = topk_rows(x.cuda(), k)
+    got_v, got_i = got_v.cpu(), got_i.cpu()
+    assert got_i.dtype == torch.int64
+    assert torch.equal(got_v, want_v)
+    assert torch.equal(torch.gather(x, 1, got_i), got_v)
+    for b in range(bs):
+        assert len(set(got_i[b].tolist())) == k
+    tie = (got_v[0, 1:] == got_v[0, :-1])
+    assert bool((got_i[0, 1:][tie] > got_i[0, :-1][tie]).all())
