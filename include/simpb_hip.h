@@ -224,6 +224,22 @@ typedef struct simpb_mlp_args {
 } simpb_mlp_args;
 int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream);
 
+/* Fixed-shape detection records of SparseBox3DDecoder.decode_with2d (models/detection3d/decoder.py:124-252).
+ * 3D (:133-167 with squeezed classes + decode_box :23-34), one workgroup per sample:
+ *   score = max_c sigmoid(cls); the num_output best anchors; re-scored by sigmoid(quality[..., 0]) (quality
+ *   may be NULL) and sorted again; rec3d f32 [bs, num_output, 14] = x y z exp(w) exp(l) exp(h) atan2(sin, cos)
+ *   vx vy vz | score | label | score before the re-score | instance id (or -1); rank_of_anchor i32 [bs, A] =
+ *   rank of the anchor in that order, or -1. cls f32 [bs, A, C]; quality f32 [bs, A, 2]; box f32 [bs, A, 11];
+ *   instance_id i64 [bs, A] or NULL. A <= 1024, num_output <= 512.
+ * 2D (:168-175 + decode_box2d :36-51), one thread per slot: rec2d f32 [bs, N2, 8] = xyxy box in original image
+ *   pixels | max_c sigmoid(cls2d) | label | rank of the slot's anchor (rank_of_anchor[q2a], or -1) | camera. */
+int simpb_decode3d_record(float* rec3d, int* rank_of_anchor, const float* cls, const float* quality, const float* box,
+                          const long long* instance_id, int batch_size, int num_anchors, int num_classes,
+                          int num_output, void* stream);
+int simpb_decode2d_record(float* rec2d, const float* cls2d, const float* box2d, const int* q2a, const int* query_cam,
+                          const int* rank_of_anchor, int batch_size, int num_query2d, int num_classes, int num_anchors,
+                          float crop_w, float crop_h, float crop_y0, float resize, void* stream);
+
 /* Top-k of each score row, sorted descending (ties: lower index first): values f32 [bs, k], indices
  * i32 [bs, k] from scores f32 [bs, n], n <= 2048, k <= n. What `topk` of models/instance_bank.py:13-20
  * and the ranking of SparseBox3DDecoder.decode (models/detection3d/decoder.py:145-167) ask of torch.topk /

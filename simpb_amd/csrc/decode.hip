@@ -1,0 +1,160 @@
+// Fixed-shape detection records of SparseBox3DDecoder.decode_with2d
+// (/root/reference/projects/mmdet3d_plugin/models/detection3d/decoder.py:124-252) in two launches.
+// In PyTorch the same work is ~40 launches of a few microseconds each at the end of every frame
+// (sigmoid, max, top-k, gathers, re-score, sort, atan2/exp, cats, scatter, ...), all on the decoder's
+// critical path because the next frame of the stream cannot start before this one has finished.
+#include <hip/hip_runtime.h>
+#include "../../include/simpb_hip.h"
+
+extern "C" int simpb_check_launch(void);
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ unsigned long long sort_key(float v, unsigned idx) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map float -> uint
+  return ((unsigned long long)u << 32) | (0xFFFFFFFFu - idx);
+}
+__device__ __forceinline__ unsigned key_index(unsigned long long k) { return 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull); }
+
+// descending bitonic sort of CAP keys held in LDS by CAP/2 (or more) threads; `nthreads` threads call it
+template <int CAP>
+__device__ __forceinline__ void bitonic_desc(unsigned long long* key, int tid, int nthreads) {
+  for (int size = 2; size <= CAP; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < CAP / 2; t += nthreads) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned long long a = key[lo], c = key[hi];
+        if ((a < c) == desc) { key[lo] = c; key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+constexpr int kCapA = 1024;  // anchors per row (900 shipped)
+constexpr int kCapK = 512;   // kept boxes per row (300 shipped)
+
+// decoder.py:133-167 (squeezed classes, quality re-score) + decode_box (:23-34), one workgroup per sample.
+__global__ __launch_bounds__(512) void decode3d_kernel(float* __restrict__ rec3d, int* __restrict__ rank_of_anchor,
+                                                       const float* __restrict__ cls, const float* __restrict__ quality,
+                                                       const float* __restrict__ box, const long long* __restrict__ instance_id,
+                                                       int A, int C, int K) {
+  __shared__ unsigned long long key[kCapA];
+  __shared__ unsigned long long key2[kCapK];
+  __shared__ int label[kCapA];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int a = tid; a < kCapA; a += 512) {
+    unsigned long long kv = 0ull;
+    if (a < A) {
+      const float* row = cls + ((size_t)b * A + a) * C;
+      float m = row[0];
+      int arg = 0;
+      for (int c = 1; c < C; ++c)
+        if (row[c] > m) { m = row[c]; arg = c; }
+      label[a] = arg;
+      kv = sort_key(sigmoidf(m), (unsigned)a);  // max of sigmoids = sigmoid of the max (monotone)
+      rank_of_anchor[(size_t)b * A + a] = -1;
+    }
+    key[a] = kv;
+  }
+  __syncthreads();
+  bitonic_desc<kCapA>(key, tid, 512);
+  // re-score the K kept boxes by centerness and sort again (:154-167); ties keep the first ranking's order
+  for (int r = tid; r < kCapK; r += 512) {
+    unsigned long long kv = 0ull;
+    if (r < K) {
+      const unsigned a = key_index(key[r]);
+      unsigned u = (unsigned)(key[r] >> 32);
+      u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+      float s = __uint_as_float(u);
+      if (quality) s *= sigmoidf(quality[((size_t)b * A + a) * 2]);
+      kv = sort_key(s, (unsigned)r);
+    }
+    key2[r] = kv;
+  }
+  __syncthreads();
+  bitonic_desc<kCapK>(key2, tid, 512);
+  for (int r = tid; r < K; r += 512) {
+    const unsigned first_rank = key_index(key2[r]);
+    const unsigned a = key_index(key[first_rank]);
+    unsigned u = (unsigned)(key2[r] >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    const float score = __uint_as_float(u);
+    // the "score before the re-score" column is NOT re-ordered by the second sort in the reference
+    // (decoder.py:157 clones it before :159-167 permute everything else): position r of the first ranking
+    unsigned uo = (unsigned)(key[r] >> 32);
+    uo = (uo & 0x80000000u) ? (uo & 0x7FFFFFFFu) : ~uo;
+    const float* bx = box + ((size_t)b * A + a) * 11;
+    float* o = rec3d + ((size_t)b * K + r) * 14;
+    o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2];
+    o[3] = expf(bx[3]); o[4] = expf(bx[4]); o[5] = expf(bx[5]);
+    o[6] = atan2f(bx[6], bx[7]);
+    o[7] = bx[8]; o[8] = bx[9]; o[9] = bx[10];
+    o[10] = score;
+    o[11] = (float)label[a];
+    o[12] = __uint_as_float(uo);
+    o[13] = instance_id ? (float)instance_id[(size_t)b * A + a] : -1.f;
+    rank_of_anchor[(size_t)b * A + a] = r;
+  }
+}
+
+// 2D half (:168-175, decode_box2d :36-51), one thread per 2D slot.
+__global__ __launch_bounds__(256) void decode2d_kernel(float* __restrict__ rec2d, const float* __restrict__ cls2d,
+                                                       const float* __restrict__ box2d, const int* __restrict__ q2a,
+                                                       const int* __restrict__ query_cam, const int* __restrict__ rank_of_anchor,
+                                                       int bs, int N2, int C, int A, float crop_w, float crop_h, float crop_y0,
+                                                       float inv_resize) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs * N2) return;
+  const int b = i / N2, slot = i - b * N2;
+  const float* row = cls2d + (size_t)i * C;
+  float m = row[0];
+  int arg = 0;
+  for (int c = 1; c < C; ++c)
+    if (row[c] > m) { m = row[c]; arg = c; }
+  const float* bx = box2d + (size_t)i * 4;
+  const float cx = bx[0], cy = bx[1], w = bx[2], h = bx[3];
+  float* o = rec2d + (size_t)i * 8;
+  o[0] = fminf(fmaxf((cx - 0.5f * w) * crop_w, 0.f), crop_w) * inv_resize;
+  o[1] = (fminf(fmaxf((cy - 0.5f * h) * crop_h, 0.f), crop_h) + crop_y0) * inv_resize;
+  o[2] = fminf(fmaxf((cx + 0.5f * w) * crop_w, 0.f), crop_w) * inv_resize;
+  o[3] = (fminf(fmaxf((cy + 0.5f * h) * crop_h, 0.f), crop_h) + crop_y0) * inv_resize;
+  o[4] = sigmoidf(m);
+  o[5] = (float)arg;
+  const int a = q2a[i];
+  o[6] = (a >= 0 && a < A) ? (float)rank_of_anchor[(size_t)b * A + a] : -1.f;
+  o[7] = (float)query_cam[slot];
+}
+
+}  // namespace
+
+extern "C" int simpb_decode3d_record(float* rec3d, int* rank_of_anchor, const float* cls, const float* quality,
+                                     const float* box, const long long* instance_id, int batch_size, int num_anchors,
+                                     int num_classes, int num_output, void* stream) {
+  if (!rec3d || !rank_of_anchor || !cls || !box || batch_size <= 0 || num_anchors <= 0 || num_anchors > kCapA ||
+      num_classes <= 0 || num_output <= 0 || num_output > kCapK || num_output > num_anchors)
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(decode3d_kernel, dim3(batch_size), dim3(512), 0, static_cast<hipStream_t>(stream), rec3d, rank_of_anchor,
+                     cls, quality, box, instance_id, num_anchors, num_classes, num_output);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_decode2d_record(float* rec2d, const float* cls2d, const float* box2d, const int* q2a,
+                                     const int* query_cam, const int* rank_of_anchor, int batch_size, int num_query2d,
+                                     int num_classes, int num_anchors, float crop_w, float crop_h, float crop_y0,
+                                     float resize, void* stream) {
+  if (!rec2d || !cls2d || !box2d || !q2a || !query_cam || !rank_of_anchor || batch_size <= 0 || num_query2d <= 0 ||
+      num_classes <= 0 || num_anchors <= 0 || resize == 0.f)
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  const int total = batch_size * num_query2d;
+  hipLaunchKernelGGL(decode2d_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rec2d, cls2d,
+                     box2d, q2a, query_cam, rank_of_anchor, batch_size, num_query2d, num_classes, num_anchors, crop_w, crop_h,
+                     crop_y0, 1.f / resize);
+  return simpb_check_launch();
+}

@@ -13,6 +13,10 @@ assert (X, Y, Z, W, L, H, SIN_YAW, COS_YAW) == tuple(range(8))
 from .layers import BaseModule, Linear, Scale, bias_init_with_prob, linear_relu_ln
 from .registry import BBOX_CODERS, PLUGIN_LAYERS, POSITIONAL_ENCODING
 
+# True: decode_static_device builds its two records with csrc/decode.hip (two launches); False: the
+# PyTorch statement of the same arithmetic (~40 launches), kept as the cross-check in tests/test_gpu_runner.py.
+FUSED_DECODE = True
+
 __all__ = ["SparseBox3DRefinementModule", "SparseBox3DKeyPointsGenerator", "SparseBox3DEncoder", "SparseBox3DDecoder"]
 
 
@@ -354,6 +358,11 @@ class SparseBox3DDecoder(object):
         rec3d = 10 decoded box + score + label + pre-centerness score + instance id (decoder.py:133-167, 23-34);
         rec2d = 4 decoded box + score + label + rank of the slot's anchor in the sorted top-k (or -1)
         + camera of the slot (or -1)."""
+        cls3, box3 = cls_scores[output_idx], box_preds[output_idx]
+        if (FUSED_DECODE and cls3.is_cuda and self.score_threshold is None and self.sorted and cls3.shape[1] <= 1024
+                and self.num_output <= 512 and box3.shape[-1] == 11 and alloc.q2a.dtype == torch.int32):
+            return self._decode_static_fused(cls3, box3, instance_id, qulity[output_idx] if qulity is not None else None,
+                                             cls_scores2d[output_idx2d], box_preds2d[output_idx2d], alloc, aug_config)
         scores, origin, cls_ids, indices, mask, num_cls = self._rank(cls_scores, qulity, output_idx, True)
         if mask is not None:
             raise NotImplementedError("score_threshold with the static decoder")
@@ -374,6 +383,33 @@ class SparseBox3DDecoder(object):
         cam = alloc.query_cam[None].expand(bs, -1)
         rec2d = torch.cat([box2d, s2d[..., None], l2d[..., None].to(box2d.dtype), slot_rank[..., None].to(box2d.dtype),
                            cam[..., None].to(box2d.dtype)], dim=-1)
+        return rec3d, rec2d
+
+    def _decode_static_fused(self, cls3, box3, instance_id, quality, cls2d, box2d, alloc, aug_config):
+        """The two records in two launches (csrc/decode.hip)."""
+        from .. import _lib
+        from .ops import _ptr, _stream
+        lib = _lib.lib()
+        bs, num_anchor, num_cls = cls3.shape
+        k = self.num_output
+        dev = cls3.device
+        cls3, box3 = cls3.contiguous().float(), box3.contiguous().float()
+        quality = quality.contiguous().float() if quality is not None else None
+        ids = instance_id.contiguous().long() if instance_id is not None else None
+        rec3d = torch.empty(bs, k, 14, device=dev)
+        rank = torch.empty(bs, num_anchor, dtype=torch.int32, device=dev)
+        _lib.check(lib.simpb_decode3d_record(_ptr(rec3d), _ptr(rank), _ptr(cls3), _ptr(quality) if quality is not None else None,
+                                             _ptr(box3), _ptr(ids) if ids is not None else None, bs, num_anchor, num_cls, k,
+                                             _stream()), "simpb_decode3d_record")
+        cls2d, box2d = cls2d.contiguous().float(), box2d.contiguous().float()
+        n2 = cls2d.shape[1]
+        rec2d = torch.empty(bs, n2, 8, device=dev)
+        crop, resize = aug_config["crop"], aug_config["resize"]
+        if n2:
+            _lib.check(lib.simpb_decode2d_record(_ptr(rec2d), _ptr(cls2d), _ptr(box2d), _ptr(alloc.q2a.contiguous()),
+                                                 _ptr(alloc.query_cam.contiguous()), _ptr(rank), bs, n2, cls2d.shape[-1],
+                                                 num_anchor, float(crop[2] - crop[0]), float(crop[3] - crop[1]),
+                                                 float(crop[1]), float(resize), _stream()), "simpb_decode2d_record")
         return rec3d, rec2d
 
     @staticmethod

@@ -326,3 +326,36 @@ def test_topk_rows_vs_torch_topk(bs, n, k):
         assert len(set(got_i[b].tolist())) == k
     tie = (got_v[0, 1:] == got_v[0, :-1])
     assert bool((got_i[0, 1:][tie] > got_i[0, :-1][tie]).all())
+
+
+@gpu
+def test_fused_decode_records_match_the_pytorch_statement():
+    """csrc/decode.hip against decode_static_device's PyTorch route (decoder.py:133-175, 23-51) on random heads."""
+    from types import SimpleNamespace
+    from simpb_amd.plugin import detection3d
+    from simpb_amd.plugin.detection3d import SparseBox3DDecoder
+    g = torch.Generator().manual_seed(31)
+    bs, A, C, N2 = 2, 900, 10, 1536
+    cls = [torch.randn(bs, A, C, generator=g).cuda()]
+    box = [torch.randn(bs, A, 11, generator=g).cuda()]
+    quality = [torch.randn(bs, A, 2, generator=g).cuda()]
+    ids = torch.randint(0, 5000, (bs, A), generator=g).cuda()
+    cls2d = [torch.randn(bs, N2, C, generator=g).cuda()]
+    box2d = [torch.rand(bs, N2, 4, generator=g).cuda()]
+    q2a = torch.randint(-1, A, (bs, N2), generator=g).to(torch.int32).cuda()
+    cam = torch.randint(-1, 6, (N2,), generator=g).to(torch.int32).cuda()
+    alloc = SimpleNamespace(q2a=q2a, query_cam=cam)
+    aug = dict(crop=(0, 140, 704, 396), resize=0.44)
+    dec = SparseBox3DDecoder(num_output=300)
+    try:
+        detection3d.FUSED_DECODE = False
+        want3, want2 = dec.decode_static_device(cls, box, ids, quality, cls2d, box2d, alloc, aug)
+        detection3d.FUSED_DECODE = True
+        got3, got2 = dec.decode_static_device(cls, box, ids, quality, cls2d, box2d, alloc, aug)
+    finally:
+        detection3d.FUSED_DECODE = True
+    assert got3.shape == want3.shape == (bs, 300, 14) and got2.shape == want2.shape == (bs, N2, 8)
+    assert float((got3 - want3).abs().max()) < 2e-4      # ids up to 5000 are exact in f32; boxes/scores ~1e-6
+    assert float((got2 - want2).abs().max()) < 2e-3      # pixel coordinates up to 1600: 1 ulp = 1.2e-4
+    assert torch.equal(got2[..., 5:], want2[..., 5:])    # label, rank, camera exactly
+    assert torch.equal(got3[..., 11], want3[..., 11]) and torch.equal(got3[..., 13], want3[..., 13])
