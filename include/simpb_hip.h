@@ -224,6 +224,32 @@ typedef struct simpb_mlp_args {
 } simpb_mlp_args;
 int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream);
 
+/* InstanceBank (models/instance_bank.py) state updates for the 11-d box state. All tensors f32 unless noted;
+ * A = instances per stream (<= 1024), T = cached instances, C = embed_dims (% 4 == 0).
+ * simpb_bank_get (:83-113): anchor_out [bs, T, 11] = cached_anchor warped by T_temp2cur [bs, 4, 4] and advanced by
+ *   its velocity over time_interval [bs] (anchor_projection with time_intervals = [-time_interval], :98-101);
+ *   mask_out u8 [bs] = |time_interval| <= max_time_interval (:87); time_interval_out [bs] = time_interval where it is
+ *   non-zero and valid, else default_time_interval (:108-113).
+ * simpb_bank_update (:121-150): rows [0, T) of the outputs = cached rows, rows [T, A) = the A - T current instances
+ *   with the largest max-class logit (cls [bs, A, num_classes]), for streams with mask != 0; other streams keep their
+ *   current rows and get their instance_id (i64 [bs, A], may be NULL) reset to -1. index_scratch i32 [bs, A - T].
+ * simpb_bank_cache (:152-196): cache() + get_instance_id() + update_instance_id(): confidence [bs, T] (in: last
+ *   frame's, used when has_previous; out: this frame's), cached_feature [bs, T, C] / cached_anchor [bs, T, 11] out,
+ *   instance_id i64 [bs, A] in/out (may be NULL), prev_id i64 [1] in/out, ids_out i64 [bs, A] = the ids
+ *   get_instance_id returns; fresh ids are numbered over the flattened batch (:179-181); threshold applies to
+ *   sigmoid(max class logit) when has_threshold. index_scratch i32 [bs, T]. */
+int simpb_bank_get(float* anchor_out, unsigned char* mask_out, float* time_interval_out, const float* cached_anchor,
+                   const float* T_temp2cur, const float* time_interval, int batch_size, int num_temp,
+                   float max_time_interval, float default_time_interval, void* stream);
+int simpb_bank_update(float* feature_out, float* anchor_out, long long* instance_id, int* index_scratch,
+                      const float* feature, const float* anchor, const float* cls, const float* cached_feature,
+                      const float* cached_anchor, const unsigned char* mask, int batch_size, int num_anchors,
+                      int num_classes, int num_temp, int embed_dims, void* stream);
+int simpb_bank_cache(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
+                     long long* prev_id, long long* ids_out, int* index_scratch, const float* feature, const float* anchor,
+                     const float* cls, int batch_size, int num_anchors, int num_classes, int num_temp, int embed_dims,
+                     int has_previous, float confidence_decay, int has_threshold, float threshold, void* stream);
+
 /* Fixed-shape detection records of SparseBox3DDecoder.decode_with2d (models/detection3d/decoder.py:124-252).
  * 3D (:133-167 with squeezed classes + decode_box :23-34), one workgroup per sample:
  *   score = max_c sigmoid(cls); the num_output best anchors; re-scored by sigmoid(quality[..., 0]) (quality

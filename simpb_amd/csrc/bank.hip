@@ -1,0 +1,248 @@
+// InstanceBank (/root/reference/projects/mmdet3d_plugin/models/instance_bank.py) state updates as a
+// handful of launches. The arithmetic is tiny (900 instances per stream); in PyTorch each of the three
+// touch points of a frame is a run of 10-45 launches of 2-5 us each on the decoder's critical path:
+//   get    (:79-119)  warp the cached anchors into the current frame, validity mask, time step
+//   update (:121-150) after the first decoder layer: [cached 600 | best 300 current]
+//   cache + get_instance_id + update_instance_id (:152-196) at the end of the frame
+#include <hip/hip_runtime.h>
+#include "../../include/simpb_hip.h"
+
+extern "C" int simpb_check_launch(void);
+
+namespace {
+
+constexpr int kCap = 1024;  // instances per stream (900 shipped)
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ unsigned long long sort_key(float v, unsigned idx) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (0xFFFFFFFFu - idx);
+}
+__device__ __forceinline__ unsigned key_index(unsigned long long k) { return 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull); }
+__device__ __forceinline__ float key_value(unsigned long long k) {
+  unsigned u = (unsigned)(k >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __uint_as_float(u);
+}
+// descending bitonic sort of kCap keys in LDS by 512 threads
+__device__ __forceinline__ void bitonic_desc(unsigned long long* key, int tid) {
+  for (int size = 2; size <= kCap; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;
+      const bool desc = (lo & size) == 0;
+      const unsigned long long a = key[lo], c = key[hi];
+      if ((a < c) == desc) { key[lo] = c; key[hi] = a; }
+      __syncthreads();
+    }
+  }
+}
+__device__ __forceinline__ float row_max(const float* row, int C) {
+  float m = row[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+  return m;
+}
+
+// ---- get (:83-113): one thread per cached anchor + one per stream for the mask / time step
+__global__ __launch_bounds__(256) void bank_get_kernel(float* __restrict__ out, unsigned char* __restrict__ mask,
+                                                       float* __restrict__ dt_out, const float* __restrict__ anchor,
+                                                       const float* __restrict__ T, const float* __restrict__ dt, int bs,
+                                                       int n, float max_dt, float default_dt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < bs) {
+    const float t = dt[i];
+    const bool ok = fabsf(t) <= max_dt;  // :87
+    mask[i] = ok ? 1 : 0;
+    dt_out[i] = (t != 0.f && ok) ? t : default_dt;  // :108-113
+  }
+  if (i >= bs * n) return;
+  const int b = i / n;
+  const float* a = anchor + (size_t)i * 11;
+  const float* m = T + (size_t)b * 16;
+  const float t = -dt[b];  // anchor_projection(..., time_intervals=[-time_interval]) (:98-101)
+  const float vx = a[8], vy = a[9], vz = a[10];
+  const float cx = a[0] - vx * t, cy = a[1] - vy * t, cz = a[2] - vz * t;
+  float* o = out + (size_t)i * 11;
+  o[0] = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
+  o[1] = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
+  o[2] = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
+  o[3] = a[3]; o[4] = a[4]; o[5] = a[5];
+  const float s = a[6], c = a[7];  // yaw pair as written in detection3d/blocks.py:271-278
+  o[6] = m[0] * c + m[1] * s;
+  o[7] = m[4] * c + m[5] * s;
+  o[8] = m[0] * vx + m[1] * vy + m[2] * vz;
+  o[9] = m[4] * vx + m[5] * vy + m[6] * vz;
+  o[10] = m[8] * vx + m[9] * vy + m[10] * vz;
+}
+
+// ---- update (:137-139): indices of the `fresh` best current instances by max class logit, one workgroup per stream
+__global__ __launch_bounds__(512) void bank_update_rank_kernel(int* __restrict__ index, const float* __restrict__ cls, int A,
+                                                               int C, int fresh) {
+  __shared__ unsigned long long key[kCap];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int a = tid; a < kCap; a += 512) key[a] = a < A ? sort_key(row_max(cls + ((size_t)b * A + a) * C, C), (unsigned)a) : 0ull;
+  __syncthreads();
+  bitonic_desc(key, tid);
+  for (int r = tid; r < fresh; r += 512) index[(size_t)b * fresh + r] = (int)key_index(key[r]);
+}
+
+// ---- update (:140-149): rows [0, T) = cached, rows [T, A) = current[index], per stream under its mask; one
+// wave per output row (feature C floats + anchor 11 floats); the ids of masked-out streams are reset (:147-149)
+__global__ __launch_bounds__(64) void bank_merge_kernel(float* __restrict__ out_f, float* __restrict__ out_a,
+                                                        long long* __restrict__ instance_id,
+                                                        const float* __restrict__ cur_f, const float* __restrict__ cur_a,
+                                                        const float* __restrict__ cached_f, const float* __restrict__ cached_a,
+                                                        const int* __restrict__ index, const unsigned char* __restrict__ mask,
+                                                        int A, int T, int C) {
+  const int r = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const bool use = mask[b] != 0;
+  const float* sf;
+  const float* sa;
+  if (!use) {
+    sf = cur_f + ((size_t)b * A + r) * C;
+    sa = cur_a + ((size_t)b * A + r) * 11;
+  } else if (r < T) {
+    sf = cached_f + ((size_t)b * T + r) * C;
+    sa = cached_a + ((size_t)b * T + r) * 11;
+  } else {
+    const int src = index[(size_t)b * (A - T) + (r - T)];
+    sf = cur_f + ((size_t)b * A + src) * C;
+    sa = cur_a + ((size_t)b * A + src) * 11;
+  }
+  float* of = out_f + ((size_t)b * A + r) * C;
+  for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(of + c) = *reinterpret_cast<const float4*>(sf + c);
+  if (lane < 11) out_a[((size_t)b * A + r) * 11 + lane] = sa[lane];
+  if (!use && instance_id && lane == 0) instance_id[(size_t)b * A + r] = -1;
+}
+
+// ---- cache (:152-167) + get_instance_id (:169-184) + update_instance_id (:186-196): ONE workgroup walks the
+// streams in order (fresh track ids are numbered over the flattened batch, :179-181).
+__global__ __launch_bounds__(512) void bank_cache_kernel(float* __restrict__ conf, int* __restrict__ index,
+                                                         long long* __restrict__ ids_out, long long* __restrict__ instance_id,
+                                                         long long* __restrict__ prev_id, const float* __restrict__ cls,
+                                                         int bs, int A, int C, int T, int has_prev, float decay,
+                                                         int has_threshold, float threshold) {
+  __shared__ unsigned long long key[kCap];
+  __shared__ long long ids[kCap];
+  __shared__ int scan[kCap];
+  __shared__ float fresh_score[kCap];
+  const int tid = threadIdx.x;
+  long long next_id = *prev_id;
+  for (int b = 0; b < bs; ++b) {
+    // scores: sigmoid of the best class; tracked instances keep max(decayed previous, new) (:157-162)
+    for (int a = tid; a < kCap; a += 512) {
+      unsigned long long kv = 0ull;
+      if (a < A) {
+        const float s = sigmoidf(row_max(cls + ((size_t)b * A + a) * C, C));
+        fresh_score[a] = s;
+        float sc = s;
+        if (has_prev && a < T) sc = fmaxf(conf[(size_t)b * T + a] * decay, s);
+        kv = sort_key(sc, (unsigned)a);
+      }
+      key[a] = kv;
+    }
+    __syncthreads();
+    bitonic_desc(key, tid);
+    for (int r = tid; r < T; r += 512) {
+      conf[(size_t)b * T + r] = key_value(key[r]);
+      index[(size_t)b * T + r] = (int)key_index(key[r]);
+    }
+    // track ids (:172-183): instances without an id (and above the threshold) get consecutive fresh ones
+    for (int a = tid; a < kCap; a += 512) {
+      long long id = -1;
+      int fresh = 0;
+      if (a < A) {
+        id = instance_id ? instance_id[(size_t)b * A + a] : -1;
+        fresh = id < 0 && (!has_threshold || fresh_score[a] >= threshold);
+      }
+      ids[a] = id;
+      scan[a] = fresh;
+    }
+    __syncthreads();
+    // inclusive scan of the 1024 flags (Hillis-Steele, 10 steps, 2 elements per thread)
+    for (int off = 1; off < kCap; off <<= 1) {
+      const int a0 = tid, a1 = tid + 512;
+      const int v0 = a0 >= off ? scan[a0 - off] : 0, v1 = scan[a1 - off];
+      __syncthreads();
+      scan[a0] += v0;
+      scan[a1] += v1;
+      __syncthreads();
+    }
+    const int total = scan[kCap - 1];
+    for (int a = tid; a < A; a += 512) {
+      const int inc = scan[a], prev = a ? scan[a - 1] : 0;
+      if (inc != prev) ids[a] = next_id + (inc - 1);
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += 512) {
+      ids_out[(size_t)b * A + a] = ids[a];
+      if (instance_id) instance_id[(size_t)b * A + a] = a < T ? ids[key_index(key[a])] : -1;  // :191-195
+    }
+    next_id += total;
+    __syncthreads();
+  }
+  if (tid == 0) *prev_id = next_id;
+}
+
+// ---- cache: kept rows of the feature / anchor tables into the persistent state, one wave per row
+__global__ __launch_bounds__(64) void bank_gather_kernel(float* __restrict__ out_f, float* __restrict__ out_a,
+                                                         const float* __restrict__ src_f, const float* __restrict__ src_a,
+                                                         const int* __restrict__ index, int A, int T, int C) {
+  const int r = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int src = index[(size_t)b * T + r];
+  const float* sf = src_f + ((size_t)b * A + src) * C;
+  float* of = out_f + ((size_t)b * T + r) * C;
+  for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(of + c) = *reinterpret_cast<const float4*>(sf + c);
+  if (lane < 11) out_a[((size_t)b * T + r) * 11 + lane] = src_a[((size_t)b * A + src) * 11 + lane];
+}
+
+}  // namespace
+
+extern "C" int simpb_bank_get(float* anchor_out, unsigned char* mask_out, float* time_interval_out, const float* cached_anchor,
+                              const float* T_temp2cur, const float* time_interval, int batch_size, int num_temp,
+                              float max_time_interval, float default_time_interval, void* stream) {
+  if (!anchor_out || !mask_out || !time_interval_out || !cached_anchor || !T_temp2cur || !time_interval || batch_size <= 0 ||
+      num_temp <= 0)
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  const int total = batch_size * num_temp;
+  hipLaunchKernelGGL(bank_get_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), anchor_out,
+                     mask_out, time_interval_out, cached_anchor, T_temp2cur, time_interval, batch_size, num_temp,
+                     max_time_interval, default_time_interval);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_bank_update(float* feature_out, float* anchor_out, long long* instance_id, int* index_scratch,
+                                 const float* feature, const float* anchor, const float* cls, const float* cached_feature,
+                                 const float* cached_anchor, const unsigned char* mask, int batch_size, int num_anchors,
+                                 int num_classes, int num_temp, int embed_dims, void* stream) {
+  if (!feature_out || !anchor_out || !index_scratch || !feature || !anchor || !cls || !cached_feature || !cached_anchor ||
+      !mask || batch_size <= 0 || num_anchors <= 0 || num_anchors > kCap || num_classes <= 0 || num_temp <= 0 ||
+      num_temp >= num_anchors || embed_dims <= 0 || (embed_dims & 3) || batch_size > 65535)
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bank_update_rank_kernel, dim3(batch_size), dim3(512), 0, s, index_scratch, cls, num_anchors, num_classes,
+                     num_anchors - num_temp);
+  hipLaunchKernelGGL(bank_merge_kernel, dim3(num_anchors, batch_size), dim3(64), 0, s, feature_out, anchor_out, instance_id,
+                     feature, anchor, cached_feature, cached_anchor, index_scratch, mask, num_anchors, num_temp, embed_dims);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_bank_cache(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
+                                long long* prev_id, long long* ids_out, int* index_scratch, const float* feature,
+                                const float* anchor, const float* cls, int batch_size, int num_anchors, int num_classes,
+                                int num_temp, int embed_dims, int has_previous, float confidence_decay, int has_threshold,
+                                float threshold, void* stream) {
+  if (!confidence || !cached_feature || !cached_anchor || !prev_id || !ids_out || !index_scratch || !feature || !anchor ||
+      !cls || batch_size <= 0 || num_anchors <= 0 || num_anchors > kCap || num_classes <= 0 || num_temp <= 0 ||
+      num_temp > num_anchors || embed_dims <= 0 || (embed_dims & 3) || batch_size > 65535)
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bank_cache_kernel, dim3(1), dim3(512), 0, s, confidence, index_scratch, ids_out, instance_id, prev_id, cls,
+                     batch_size, num_anchors, num_classes, num_temp, has_previous, confidence_decay, has_threshold, threshold);
+  hipLaunchKernelGGL(bank_gather_kernel, dim3(num_temp, batch_size), dim3(64), 0, s, cached_feature, cached_anchor, feature,
+                     anchor, index_scratch, num_anchors, num_temp, embed_dims);
+  return simpb_check_launch();
+}

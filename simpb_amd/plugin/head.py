@@ -338,8 +338,11 @@ class SimPBHead(BaseModule):
             "ref_trans_matrix_list": ref_trans_matrix_list, "ref_query_groups_list": ref_query_groups_list,
             "alloc_list": alloc_list,
         }
-        self.instance_bank.cache(instance_feature, anchor, cls, metas, feature_maps)
-        output["instance_id"] = self.instance_bank.get_instance_id(cls, anchor, self.decoder.score_threshold)
+        ids = self.instance_bank.cache_and_assign_ids(instance_feature, anchor, cls, metas, self.decoder.score_threshold)
+        if ids is None:
+            self.instance_bank.cache(instance_feature, anchor, cls, metas, feature_maps)
+            ids = self.instance_bank.get_instance_id(cls, anchor, self.decoder.score_threshold)
+        output["instance_id"] = ids
         return output
 
     def loss(self, model_outs, data):

@@ -8,9 +8,16 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import _lib
+from .ops import _ptr, _stream
 from .registry import PLUGIN_LAYERS, build_from_cfg
 
 __all__ = ["InstanceBank"]
+
+# True: with the persistent (static) state the three touch points of a frame run as csrc/bank.hip launches
+# (1 + 2 + 2) instead of ~70 PyTorch launches; False: the PyTorch statement below, which is also what the
+# eager (non-static) mode always runs and what tests compare the kernels with.
+FUSED_BANK = True
 
 _STATE_FIELDS = ("cached_feature", "cached_anchor", "confidence", "instance_id", "prev_id")
 
@@ -131,6 +138,21 @@ class InstanceBank(nn.Module):
             self.reset()
             dt = feature.new_full((batch_size,), self.default_time_interval)
             return feature, anchor, self.cached_feature, self.cached_anchor, dt
+        if static_warm and self._fusable(self._static["cached_anchor"]):
+            T_temp2cur, dt = metas["bank_inputs"]
+            stored = self._static["cached_anchor"]
+            self.cached_feature = self._static["cached_feature"]
+            bs, t = stored.shape[:2]
+            warped = torch.empty_like(stored)
+            self.mask = torch.empty(bs, dtype=torch.bool, device=stored.device)
+            dt_out = torch.empty(bs, dtype=torch.float32, device=stored.device)
+            lib = _lib.lib()
+            _lib.check(lib.simpb_bank_get(_ptr(warped), _ptr(self.mask), _ptr(dt_out), _ptr(stored),
+                                          _ptr(T_temp2cur.contiguous().float()), _ptr(dt.contiguous().float()), bs, t,
+                                          float(self.max_time_interval), float(self.default_time_interval), _stream()),
+                       "simpb_bank_get")
+            self.cached_anchor = warped
+            return feature, anchor, self.cached_feature, self.cached_anchor, dt_out
         if static_warm:
             # T_temp2cur and the raw time step were prepared on the host by the caller (they depend on
             # metadata only) and already sit in device buffers
@@ -155,6 +177,23 @@ class InstanceBank(nn.Module):
             return instance_feature, anchor
         if instance_feature.shape[1] > self.num_anchor:
             raise NotImplementedError("denoising instances only exist in training")
+        if (self._fusable(instance_feature) and self.mask is not None and self.mask.dtype == torch.bool
+                and instance_feature.shape[1] == self.num_anchor):
+            bs, a, c = instance_feature.shape
+            t = self.num_temp_instances
+            out_f = torch.empty(bs, a, c, device=instance_feature.device)
+            out_a = torch.empty(bs, a, anchor.shape[-1], device=instance_feature.device)
+            scratch = torch.empty(bs, a - t, dtype=torch.int32, device=instance_feature.device)
+            ids = self.instance_id if self.instance_id is self._static["instance_id"] else None
+            cls = confidence.contiguous().float()
+            _lib.check(_lib.lib().simpb_bank_update(
+                _ptr(out_f), _ptr(out_a), _ptr(ids) if ids is not None else None, _ptr(scratch),
+                _ptr(instance_feature.contiguous().float()), _ptr(anchor.contiguous().float()), _ptr(cls),
+                _ptr(self.cached_feature.contiguous()), _ptr(self.cached_anchor.contiguous()), _ptr(self.mask), bs, a,
+                cls.shape[-1], t, c, _stream()), "simpb_bank_update")
+            if ids is None and self.instance_id is not None:
+                self._keep("instance_id", self.instance_id.masked_fill(~self.mask[:, None], -1))
+            return out_f, out_a
         fresh = self.num_anchor - self.num_temp_instances
         _, (best_feature, best_anchor) = topk(confidence.max(dim=-1).values, fresh, instance_feature, anchor)
         merged_feature = torch.cat([self.cached_feature, best_feature], dim=1)
@@ -186,6 +225,37 @@ class InstanceBank(nn.Module):
         self._keep("cached_feature", kept_feature)
         self._keep("cached_anchor", kept_anchor)
         self.has_history = True
+
+    def _fusable(self, t):
+        return (FUSED_BANK and self._static is not None and t.is_cuda and self.anchor.shape[-1] == 11
+                and self.num_anchor <= 1024 and 0 < self.num_temp_instances < self.num_anchor
+                and self.embed_dims % 4 == 0)
+
+    def cache_and_assign_ids(self, instance_feature, anchor, confidence, metas=None, threshold=None):
+        """cache() followed by get_instance_id() (simpb_head.py:744-747) on the persistent state, as two
+        launches (csrc/bank.hip). Returns the instance ids, or None when the fused route does not apply
+        (the caller then runs the two methods)."""
+        if not self._fusable(instance_feature) or instance_feature.shape[1] != self.num_anchor:
+            return None
+        st = self._static
+        bs, a, c = instance_feature.shape
+        t = self.num_temp_instances
+        cls = confidence.detach().contiguous().float()
+        ids_out = torch.empty(bs, a, dtype=torch.long, device=cls.device)
+        scratch = torch.empty(bs, t, dtype=torch.int32, device=cls.device)
+        has_prev = self.confidence is not None
+        _lib.check(_lib.lib().simpb_bank_cache(
+            _ptr(st["confidence"]), _ptr(st["cached_feature"]), _ptr(st["cached_anchor"]), _ptr(st["instance_id"]),
+            _ptr(st["prev_id"]), _ptr(ids_out), _ptr(scratch), _ptr(instance_feature.detach().contiguous().float()),
+            _ptr(anchor.detach().contiguous().float()), _ptr(cls), bs, a, cls.shape[-1], t, c, 1 if has_prev else 0,
+            float(self.confidence_decay), 0 if threshold is None else 1, 0.0 if threshold is None else float(threshold),
+            _stream()), "simpb_bank_cache")
+        self.metas = metas
+        self.confidence, self.cached_feature, self.cached_anchor = st["confidence"], st["cached_feature"], st["cached_anchor"]
+        self.instance_id, self.prev_id = st["instance_id"], st["prev_id"]
+        self.temp_confidence = self._kept_index = None
+        self.has_history = True
+        return ids_out
 
     def get_instance_id(self, confidence, anchor=None, threshold=None):
         """Track ids: tracked instances keep theirs, the others get fresh consecutive ids

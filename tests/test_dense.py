@@ -359,3 +359,66 @@ def test_fused_decode_records_match_the_pytorch_statement():
     assert float((got2 - want2).abs().max()) < 2e-3      # pixel coordinates up to 1600: 1 ulp = 1.2e-4
     assert torch.equal(got2[..., 5:], want2[..., 5:])    # label, rank, camera exactly
     assert torch.equal(got3[..., 11], want3[..., 11]) and torch.equal(got3[..., 13], want3[..., 13])
+
+
+@gpu
+def test_fused_bank_matches_the_pytorch_bank_over_a_stream():
+    """csrc/bank.hip (get / update / cache + ids on the persistent state) against the PyTorch statement of
+    instance_bank.py:79-196 run on the same static state, 4 frames, 2 streams, one stream with a stale gap."""
+    from simpb_amd.plugin import instance_bank as ib
+    from simpb_amd import synth
+    g = torch.Generator().manual_seed(41)
+    bs, A, T, C = 2, 900, 600, 256
+
+    def make():
+        bank = ib.InstanceBank(num_anchor=A, embed_dims=C, anchor=synth.anchors(A), num_temp_instances=T,
+                               anchor_handler=dict(type="SparseBox3DKeyPointsGenerator"), confidence_decay=0.6,
+                               feat_grad=False).cuda().eval()
+        bank.enable_static(bs, torch.device("cuda"))
+        return bank
+
+    frames = []
+    for f in range(4):
+        Tm = torch.eye(4).repeat(bs, 1, 1)
+        Tm[:, :3, 3] = torch.randn(bs, 3, generator=g)
+        ang = torch.randn(bs, generator=g) * 0.2
+        Tm[:, 0, 0], Tm[:, 0, 1], Tm[:, 1, 0], Tm[:, 1, 1] = ang.cos(), -ang.sin(), ang.sin(), ang.cos()
+        dt = torch.tensor([0.5, 3.0 if f == 2 else 0.5])       # stream 1 goes stale once (|dt| > 2)
+        frames.append(dict(T=Tm.cuda(), dt=dt.cuda(), feat1=torch.randn(bs, A, C, generator=g).cuda(),
+                           anchor1=torch.randn(bs, A, 11, generator=g).cuda(), cls1=torch.randn(bs, A, 10, generator=g).cuda(),
+                           feat2=torch.randn(bs, A, C, generator=g).cuda(), anchor2=torch.randn(bs, A, 11, generator=g).cuda(),
+                           cls2=torch.randn(bs, A, 10, generator=g).cuda()))
+
+    def run(fused):
+        ib.FUSED_BANK = fused
+        bank, out = make(), []
+        with torch.no_grad():
+            for f, fr in enumerate(frames):
+                metas = {"bank_inputs": (fr["T"], fr["dt"])} if f else {}
+                _, _, cf, ca, dt = bank.get(bs, metas)
+                rec = dict(dt=dt.clone(), ca=None if ca is None else ca.clone())
+                feat, anc = bank.update(fr["feat1"], fr["anchor1"], fr["cls1"])
+                rec.update(feat=feat.clone(), anc=anc.clone())
+                ids = bank.cache_and_assign_ids(fr["feat2"], fr["anchor2"], fr["cls2"], metas={}, threshold=None)
+                if ids is None:
+                    bank.cache(fr["feat2"], fr["anchor2"], fr["cls2"], metas={})
+                    ids = bank.get_instance_id(fr["cls2"], fr["anchor2"], None)
+                rec.update(ids=ids.clone(), conf=bank.confidence.clone(), cfeat=bank.cached_feature.clone(),
+                           canc=bank.cached_anchor.clone(), kept=bank.instance_id.clone(), prev=int(bank.prev_id))
+                out.append(rec)
+        return out
+
+    try:
+        want, got = run(False), run(True)
+    finally:
+        ib.FUSED_BANK = True
+    for f, (w, gt) in enumerate(zip(want, got)):
+        for k in w:
+            if w[k] is None:
+                assert gt[k] is None
+            elif isinstance(w[k], int):
+                assert w[k] == gt[k], (f, k)
+            elif w[k].dtype == torch.long:
+                assert torch.equal(w[k], gt[k]), (f, k)
+            else:
+                assert float((w[k] - gt[k]).abs().max()) < 1e-5, (f, k)
