@@ -42,42 +42,42 @@ __global__ __launch_bounds__(256) void anchor_projection_kernel(float* __restric
 }
 
 // ---- operands of the grouped multi-scale deformable attention from the fused projection
-// (group_attn.py:181-201): one thread per (query slot, head). raw row = [offsets heads*L*P*2 |
-// logits heads*L*P]; attention = softmax over the L*P logits of the head; location = reference point
-// + offset / (W_l, H_l).
+// (group_attn.py:181-201): one thread per (query slot, head, level*point) element, coalesced; the
+// softmax over the L*P (= 16 shipped) logits of a head is a 16-lane reduction. raw row = [offsets
+// heads*L*P*2 | logits heads*L*P]; location = reference point + offset / (W_l, H_l).
+template <int LP>
 __global__ __launch_bounds__(256) void msda_prep_kernel(float* __restrict__ loc, float* __restrict__ attn,
                                                         const float* __restrict__ raw, int ldraw,
                                                         const float* __restrict__ ref, int ldref,
                                                         const long long* __restrict__ spatial_shapes, int rows,
-                                                        int heads, int L, int P, const int* __restrict__ m_live) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * heads) return;
-  const int q = i / heads, h = i - q * heads;
-  const int LP = L * P;
-  float* lo = loc + (size_t)i * LP * 2;
-  float* at = attn + (size_t)i * LP;
+                                                        int heads, int P, const int* __restrict__ m_live) {
+  const int per_row = heads * LP;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(i / per_row), e = (int)(i - (long long)q * per_row);  // e = head * LP + level * P + point
+  const bool in = q < rows;
   const int live = m_live ? *m_live : rows;
-  if (q >= live) {  // capacity slot: defined values, never sampled (query_cam = -1)
-    for (int j = 0; j < LP; ++j) { lo[2 * j] = 0.f; lo[2 * j + 1] = 0.f; at[j] = 0.f; }
-    return;
+  const bool alive = in && q < live;
+  float lg = -INFINITY, ox = 0.f, oy = 0.f, rx = 0.f, ry = 0.f, wl = 1.f, hl = 1.f;
+  if (alive) {
+    const float* r = raw + (size_t)q * ldraw;
+    const float2 o = *reinterpret_cast<const float2*>(r + 2 * e);
+    ox = o.x; oy = o.y;
+    lg = r[2 * per_row + e];
+    rx = ref[(size_t)q * ldref]; ry = ref[(size_t)q * ldref + 1];
+    const int l = (e % LP) / P;
+    hl = (float)spatial_shapes[2 * l]; wl = (float)spatial_shapes[2 * l + 1];
   }
-  const float* off = raw + (size_t)q * ldraw + h * LP * 2;
-  const float* lg = raw + (size_t)q * ldraw + heads * LP * 2 + h * LP;
-  const float rx = ref[(size_t)q * ldref], ry = ref[(size_t)q * ldref + 1];
-  float mx = lg[0];
-  for (int j = 1; j < LP; ++j) mx = fmaxf(mx, lg[j]);
-  float sum = 0.f;
-  for (int j = 0; j < LP; ++j) sum += expf(lg[j] - mx);
-  const float inv = 1.f / sum;
-  for (int l = 0; l < L; ++l) {
-    const float Hf = (float)spatial_shapes[2 * l], Wf = (float)spatial_shapes[2 * l + 1];
-    for (int p = 0; p < P; ++p) {
-      const int j = l * P + p;
-      lo[2 * j] = rx + off[2 * j] / Wf;
-      lo[2 * j + 1] = ry + off[2 * j + 1] / Hf;
-      at[j] = expf(lg[j] - mx) * inv;
-    }
-  }
+  float mx = lg;
+#pragma unroll
+  for (int m = LP / 2; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+  const float ex = alive ? expf(lg - mx) : 0.f;
+  float sum = ex;
+#pragma unroll
+  for (int m = LP / 2; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+  if (!in) return;
+  const size_t o = (size_t)q * per_row + e;
+  reinterpret_cast<float2*>(loc)[o] = alive ? make_float2(rx + ox / wl, ry + oy / hl) : make_float2(0.f, 0.f);
+  attn[o] = alive ? ex / sum : 0.f;
 }
 
 // ---- ReWeight.alpha (aggregation.py:23-24): one wave per row
@@ -185,10 +185,22 @@ extern "C" int simpb_msda_prep(float* sampling_loc, float* attn_weight, const fl
   if (!sampling_loc || !attn_weight || !raw || !ref || !spatial_shapes || num_rows <= 0 || num_heads <= 0 ||
       num_levels <= 0 || num_points <= 0 || ldraw < num_heads * num_levels * num_points * 3 || ldref < 2)
     return SIMPB_EINVAL;
+  const int lp = num_levels * num_points;
+  if ((lp != 16 && lp != 32 && lp != 8) || (ldraw & 1) || (reinterpret_cast<size_t>(raw) & 7) ||
+      (reinterpret_cast<size_t>(sampling_loc) & 7))
+    return SIMPB_EINVAL;  // the softmax is a power-of-two lane-group reduction
   (void)hipGetLastError();
-  const int total = num_rows * num_heads;
-  hipLaunchKernelGGL(msda_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     sampling_loc, attn_weight, raw, ldraw, ref, ldref, spatial_shapes, num_rows, num_heads, num_levels,
-                     num_points, m_live);
+  const long long total = (long long)num_rows * num_heads * lp;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (lp == 16)
+    hipLaunchKernelGGL(msda_prep_kernel<16>, grid, block, 0, s, sampling_loc, attn_weight, raw, ldraw, ref, ldref,
+                       spatial_shapes, num_rows, num_heads, num_points, m_live);
+  else if (lp == 32)
+    hipLaunchKernelGGL(msda_prep_kernel<32>, grid, block, 0, s, sampling_loc, attn_weight, raw, ldraw, ref, ldref,
+                       spatial_shapes, num_rows, num_heads, num_points, m_live);
+  else
+    hipLaunchKernelGGL(msda_prep_kernel<8>, grid, block, 0, s, sampling_loc, attn_weight, raw, ldraw, ref, ldref,
+                       spatial_shapes, num_rows, num_heads, num_points, m_live);
   return simpb_check_launch();
 }
