@@ -1,0 +1,41 @@
+"""MFMA utilisation of the matrix kernels from a rocprofv3 --pmc counter_collection csv (streamed: the
+file can be hundreds of MB). usage: mfma_util.py counter_collection.csv out.json"""
+import collections
+import csv
+import json
+import sys
+
+NAMES = {"gemm_f32_kernel<64": "gemm_f32_kernel<64,4,64>", "gemm_f32_kernel<32, 2": "gemm_f32_kernel<32,2,128>",
+         "gemm_f32_kernel<32, 4": "gemm_f32_kernel<32,4,64>", "attention_f32_kernel<false": "attention_f32_kernel<false>",
+         "attention_f32_kernel<true": "attention_f32_kernel<true>", "mlp_chain_mfma": "mlp_chain_mfma_kernel",
+         "linear_f32_mfma": "linear_f32_mfma (value_proj)"}
+per = collections.defaultdict(dict)
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        for k, v in NAMES.items():
+            if k in r["Kernel_Name"]:
+                d = per[(v, r["Dispatch_Id"])]
+                d[r["Counter_Name"]] = float(r["Counter_Value"])
+                d["dur"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                break
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for (k, _), c in per.items():
+    if c.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        agg[k]["util"].append(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024))
+        agg[k]["dur"].append(c["dur"])
+        w = max(c.get("SQ_WAVE_CYCLES", 1), 1)
+        agg[k]["stall"].append(c.get("SQ_WAIT_INST_ANY", 0) / w)
+        agg[k]["wait"].append(c.get("SQ_WAIT_ANY", 0) / w)
+out = {}
+for k, v in agg.items():
+    n = len(v["util"])
+    out[k] = dict(dispatches=n, mfma_busy_fraction=round(sum(v["util"]) / n, 4), avg_us_under_pmc=round(sum(v["dur"]) / n, 2),
+                  wave_cycles_in_issue_stall=round(sum(v["stall"]) / n, 3), wave_cycles_waiting=round(sum(v["wait"]) / n, 3))
+    print(k, out[k])
+json.dump(dict(
+    command="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE "
+            "-- python bench.py --steps 10 --warmup 3 --no-cpu-baseline", round=1,
+    definition="mfma_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs) per dispatch, averaged "
+               "(the guide's MfmaUtil); every kernel here is exact fp32 on v_mfma_f32_32x32x2 / 16x16x4 (peak 157.3 TFLOP/s). "
+               "Counters serialise the two HIP streams of the pipelined frame, so durations are per-kernel, not in-frame.",
+    kernels=out), open(sys.argv[2], "w"), indent=1)
