@@ -161,11 +161,11 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
     });
   };
 
-  // two accumulators per wave (even / odd k steps): consecutive matrix instructions of a wave do not
-  // depend on each other; they are added once at the end
-  f32x16 acc, acc_odd;
+  // one accumulator per wave (two, for even / odd k steps, measured no faster and cost 16 registers:
+  // at <= 80 VGPRs three 8-wave workgroups fit a CU instead of two)
+  f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_odd[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   auto multiply = [&](int buf) __attribute__((always_inline)) {
     // lane (r32, half) holds k = wk*KW + half*KH + 0..KH-1 of its x row and of its W row: the same
@@ -181,10 +181,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
       b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
     }
 #pragma unroll
-    for (int s = 0; s < KH; s += 2) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-      acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s + 1], b[s + 1], acc_odd, 0, 0, 0);
-    }
+    for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
   };
 
   // DEPTH register sets = DEPTH chunks in flight ahead of the one being multiplied: the operands
@@ -213,8 +210,6 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
   __syncthreads();
   float* part = smem;  // [WK][BM][LDP]
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] += acc_odd[r];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -319,7 +314,7 @@ extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
   dim3 grid(L.per_xcd * 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (bn == 64)
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 4, 64>), grid, dim3(kThreads), 0, s, L);
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 2, 64>), grid, dim3(kThreads), 0, s, L);
   else if (wide_k)  // 32-wide tiles: 128-deep chunks halve the barriers per matrix instruction (LDS 66 KB, 2 workgroups per CU)
     hipLaunchKernelGGL((gemm_f32_kernel<32, 2, 128>), grid, dim3(kThreads), 0, s, L);
   else

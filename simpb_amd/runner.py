@@ -138,8 +138,11 @@ class PipelinedRunner(FrameRunner):
     def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True):
         super().__init__(model, batch_size, image_hw, capacity, device, use_graph)
         dev = self.device
-        self.s_bb = torch.cuda.Stream(device=dev)
-        self.s_head = torch.cuda.Stream(device=dev)
+        # the decoder of frame t is the critical path (a chain of ~170 dependent small launches); the
+        # backbone of frame t+1 only has to be done by the time that chain ends: decoder stream first
+        prio = getattr(self, "STREAM_PRIORITIES", (0, -1))
+        self.s_bb = torch.cuda.Stream(device=dev, priority=prio[0])
+        self.s_head = torch.cuda.Stream(device=dev, priority=prio[1])
         self.imgs = [self.img, torch.zeros_like(self.img)]
         self.fm = [None, None]              # feature maps of the frame last produced into each slot
         self.bb_graph = [None, None]
