@@ -101,6 +101,14 @@ int simpb_ms_deform_attn_grouped_backward(
 int simpb_linear_f32(float* y, const float* x, const float* weight, const float* bias, int M, int N, int K,
                      int relu, void* stream);
 
+/* Same product on the FP16 matrix cores at fp32-grade accuracy: weight = weight_hi + weight_lo / 2048 with both parts
+ * f16 [N, K] (weight_hi = half(weight), weight_lo = half((weight - weight_hi) * 2048), prepared once by the caller);
+ * x is split the same way while it is staged; y = x_hi.W_hi^T + (x_hi.W_lo^T + x_lo.W_hi^T) / 2048 + bias in fp32
+ * accumulators (the dropped x_lo.W_lo^T term is ~2^-22 relative). Requires |x|, |weight| < 65504. Used for value_proj
+ * (models/group_attn.py:176), where the exact kernel above is compute-bound. K % 32 == 0; 16-byte aligned. */
+int simpb_linear_f16x3(float* y, const float* x, const void* weight_hi, const void* weight_lo, const float* bias, int M,
+                       int N, int K, void* stream);
+
 /* Grouped small GEMM of the decoder: up to 4 independent problems per launch, each
  *   y[M, 0:N] (row stride ldy) = relu?( [x0 | x1 | ...][M, K] . w[N, K]^T (row stride ldw) + bias[N] )
  * where x is given as up to 4 column segments (pointer, row stride, width; widths sum to K). This is

@@ -22,6 +22,7 @@ SIGNATURES = {
     "simpb_ms_deform_attn_grouped_forward": ([_P] * 7 + [_I] * 8 + [_P], _I),
     "simpb_ms_deform_attn_grouped_backward": ([_P] * 10 + [_I] * 8 + [_P], _I),
     "simpb_linear_f32": ([_P] * 4 + [_I] * 4 + [_P], _I),
+    "simpb_linear_f16x3": ([_P] * 5 + [_I] * 3 + [_P], _I),
     "simpb_gemm_f32": ([_P, _P], _I),
     "simpb_layernorm_f32": ([_P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P], _I),
     "simpb_bias_act_nhwc_f16": ([_P, _P, _P, ctypes.c_longlong, _I, _I, _P], _I),

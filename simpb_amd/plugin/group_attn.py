@@ -7,7 +7,9 @@ import torch.nn as nn
 
 from . import dense
 from .layers import BaseModule, build_dropout, mha_forward
-from .ops import linear_f32, ms_deform_attn_grouped, query_cam_from_groups
+from .ops import linear_f32, linear_split, ms_deform_attn_grouped, query_cam_from_groups
+
+SPLIT_VALUE_PROJ = True  # False: the exact-fp32 matrix-core kernel (csrc/linear.hip), 3.5x slower on this shape
 from .registry import ATTENTION
 
 
@@ -100,7 +102,10 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
 
     def project_value(self, value, key_padding_mask=None):
         """value_proj over every camera token (:176-179): the largest GEMM of the decoder."""
-        value = linear_f32(value, self.value_proj.weight, self.value_proj.bias)
+        # fp32-grade product on the FP16 matrix cores (three split passes); the camera tokens are the output of
+        # the fp16 backbone, well inside the half-precision range the split needs
+        lin = linear_split if SPLIT_VALUE_PROJ else linear_f32
+        value = lin(value, self.value_proj.weight, self.value_proj.bias)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         return value

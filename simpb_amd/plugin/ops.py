@@ -344,3 +344,33 @@ def topk_rows(scores, k):
         _lib.check(_lib.lib().simpb_topk_rows(_ptr(values), _ptr(index), _ptr(scores), bs, n, k, _stream()),
                    "simpb_topk_rows")
     return values, index.long()
+
+
+_split_cache = {}
+
+
+def linear_split(x, weight, bias=None):
+    """F.linear(x, weight, bias) at fp32-grade accuracy on the FP16 matrix cores (csrc/linear_split.hip):
+    both operands split into a leading and a 2^11-scaled trailing half-precision part, three products in
+    fp32 accumulators. |x|, |weight| must be below the half-precision range. x [..., K], weight [N, K]."""
+    _require_gpu(x, weight)
+    k = x.shape[-1]
+    if weight.shape[1] != k or k % 32:
+        raise ValueError("linear_split: x [..., K], weight [N, K], K a multiple of 32")
+    tag = (weight.data_ptr(), weight._version, str(weight.device))
+    hit = _split_cache.get(id(weight))
+    if hit is None or hit[0] != tag:
+        with torch.no_grad():
+            w = weight.detach().float()
+            hi = w.half()
+            lo = ((w - hi.float()) * 2048.0).half()
+        hit = (tag, hi.contiguous(), lo.contiguous())
+        _split_cache[id(weight)] = hit
+    x2 = x.contiguous().float().reshape(-1, k)
+    m, n = x2.shape[0], weight.shape[0]
+    y = torch.empty(m, n, device=x.device, dtype=torch.float32)
+    b = bias.contiguous().float() if bias is not None else None
+    if m:
+        _lib.check(_lib.lib().simpb_linear_f16x3(_ptr(y), _ptr(x2), _ptr(hit[1]), _ptr(hit[2]), _ptr(b) if b is not None else None,
+                                                 m, n, k, _stream()), "simpb_linear_f16x3")
+    return y.reshape(x.shape[:-1] + (n,))

@@ -422,3 +422,22 @@ def test_fused_bank_matches_the_pytorch_bank_over_a_stream():
                 assert torch.equal(w[k], gt[k]), (f, k)
             else:
                 assert float((w[k] - gt[k]).abs().max()) < 1e-5, (f, k)
+
+
+@gpu
+@pytest.mark.parametrize("m,scale", [(89760, 1.0), (1000, 1e-3), (77, 100.0)])
+def test_linear_split_fp16_passes_reach_fp32_accuracy(m, scale):
+    """csrc/linear_split.hip against float64, same bound as the exact fp32 kernel (2e-5 * max|ref|), on
+    small, unit and large magnitudes (the trailing parts are scaled, so small inputs do not underflow)."""
+    from simpb_amd.plugin.ops import linear_f32, linear_split
+    g = torch.Generator().manual_seed(m)
+    x = (torch.randn(m, 256, generator=g) * scale)
+    w = torch.randn(256, 256, generator=g) / 16
+    b = torch.randn(256, generator=g) * scale
+    want = x.double() @ w.double().t() + b.double()
+    got = linear_split(x.cuda(), w.cuda(), b.cuda()).cpu()
+    exact = linear_f32(x.cuda(), w.cuda(), b.cuda()).cpu()
+    bound = 2e-5 * float(want.abs().max())
+    assert float((got.double() - want).abs().max()) <= bound
+    # and no worse than 4x the exact kernel's own rounding error
+    assert float((got.double() - want).abs().max()) <= 4 * float((exact.double() - want).abs().max()) + 1e-7 * scale
