@@ -137,6 +137,12 @@ typedef struct simpb_gemm_job {
    * cat(query2d, is_center)) without materialising the concatenation. Both NULL = absent. */
   const int* row_flag;
   const float* bias2;
+  /* optional pre-split weights, f16 [N, K] with dense rows: w_hi = half(w), w_lo = half((w - w_hi) * 2048). When every
+   * job of a launch brings them (and its segment widths are multiples of 128) the products run on the FP16 matrix
+   * cores in three passes at fp32-grade accuracy (see simpb_linear_f16x3); `w` stays the reference copy. Needs
+   * |x|, |w| < 65504. Both NULL = exact fp32 path. */
+  const void* w_hi;
+  const void* w_lo;
 } simpb_gemm_job;
 typedef struct simpb_gemm_args {
   int num_jobs;

@@ -24,13 +24,38 @@ MAX_SEGS, MAX_JOBS = 4, 4
 # on which tests/test_gpu_head.py compares every golden trace record.
 ENABLED = True
 
+# True: weights are also handed over split into two half-precision parts, and launches whose segments are
+# 128-aligned run on the FP16 matrix cores in four split passes at fp32-grade accuracy (csrc/gemm.hip:
+# gemm_f16x3_kernel; 25-35 % faster per launch, tests/test_dense.py bounds its error like the exact kernel's).
+# False (default): always the exact fp32 matrix-core kernel. Off by default because the gain at frame level is
+# small (296 -> 301 frames/s: the launches are latency-, not matrix-bound) and because a different -- equally
+# accurate -- rounding moved one 2D query of the golden R50 stream across the image border (N2 1129 vs 1130 in one
+# layer of one frame): the allocation's inside/outside tests sit downstream of every product, ~1e-6 of the 583k
+# point tests of a stream fall within rounding distance of a border, and the golden vectors were matched
+# slot for slot with the exact kernels.
+SPLIT_FP16 = False
+_split_cache = {}
+
+
+def _split_weights(w):
+    """(w_hi, w_lo) f16 [N, K] of a contiguous f32 weight: w = w_hi + w_lo / 2048 up to ~2^-22 relative."""
+    key = (w.data_ptr(), tuple(w.shape), str(w.device))
+    hit = _split_cache.get(key)
+    if hit is None or hit[0] != w._version:
+        with torch.no_grad():
+            hi = w.detach().half()
+            lo = ((w.detach() - hi.float()) * 2048.0).half()
+        hit = (w._version, hi.contiguous(), lo.contiguous())
+        _split_cache[key] = hit
+    return hit[1], hit[2]
+
 
 class _Job(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p * MAX_SEGS), ("ldx", ctypes.c_int * MAX_SEGS), ("kseg", ctypes.c_int * MAX_SEGS),
                 ("num_seg", ctypes.c_int), ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
                 ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p), ("m_live", ctypes.c_void_p),
                 ("ldw", ctypes.c_int), ("ldy", ctypes.c_int), ("relu", ctypes.c_int), ("reserved", ctypes.c_int),
-                ("row_flag", ctypes.c_void_p), ("bias2", ctypes.c_void_p)]
+                ("row_flag", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p)]
 
 
 class _Args(ctypes.Structure):
@@ -147,6 +172,10 @@ def gemm(*jobs):
             bias = bias.float().contiguous()
         jb.num_seg, jb.M, jb.N, jb.K = len(spec["xs"]), m, n, k
         jb.w, jb.ldw = w.data_ptr(), w.stride(0)
+        if SPLIT_FP16 and w.is_contiguous() and all(x.shape[-1] % 128 == 0 for x in spec["xs"]):
+            w_hi, w_lo = _split_weights(w)
+            jb.w_hi, jb.w_lo = w_hi.data_ptr(), w_lo.data_ptr()
+            keep += [w_hi, w_lo]
         jb.bias = bias.data_ptr() if bias is not None else None
         jb.y, jb.ldy = out.data_ptr(), ldo
         jb.relu = 1 if spec["relu"] else 0

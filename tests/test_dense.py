@@ -108,7 +108,10 @@ def _ref(xs, w, b, relu):
     (33, 100, [64], True, False),                # ragged everything, single chunk
     (65, 70, [64, 64, 64, 64], False, True),     # four segments
 ])
-def test_gemm_vs_float64(m, n, ks, relu, bias):
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_fp16"])
+def test_gemm_vs_float64(m, n, ks, relu, bias, split, monkeypatch):
+    """split_fp16: the FP16-matrix-core variant (used when every segment is 128-aligned) must meet the same bound."""
+    monkeypatch.setattr(dense, "SPLIT_FP16", split)
     rs = torch.Generator().manual_seed(m * 7 + n)
     xs = [torch.randn(m, k, generator=rs) for k in ks]
     w = torch.randn(n, sum(ks), generator=rs) / np.sqrt(sum(ks))
