@@ -174,6 +174,17 @@ int simpb_format_tokens(float* col_feats, const void* const* level_ptrs, const i
 int simpb_bias_act_nhwc_f16(void* y, const void* bias, const void* residual, long long num_pixels, int channels,
                             int relu, void* stream);
 
+/* A whole BN-folded 1x1 convolution of the fp16 channels_last backbone in one launch:
+ *   y[n, ho, wo, :] = relu?( x[n, ho*stride, wo*stride, :] . weight^T + bias (+ residual[n, ho, wo, :]) )
+ * x f16 [num_images, in_h, in_w, in_channels] (NHWC), weight f16 [out_channels, in_channels], bias f16 [out_channels],
+ * residual f16 like y or NULL, y f16 [num_images, ho, wo, out_channels] with ho = (in_h - 1) / stride + 1; fp32
+ * accumulate. stride 1 or 2; in_channels % 32 == 0, out_channels % 8 == 0; 16-byte aligned. These are conv1 / conv3 /
+ * downsample of every ResNet bottleneck and the FPN lateral convolutions (mmdet ResNet + FPN of
+ * projects/configs/simpb_nus_r50_img_704x256.py:79-99 after tools/fuse_conv_bn.py:10-48). */
+int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const void* bias, const void* residual,
+                           int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride, int relu,
+                           void* stream);
+
 /* Attention core of torch.nn.MultiheadAttention (between in_proj and out_proj), exact fp32, flash
  * style, head_dim = 64: out[b,q,h*64+d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d].
  * q/k/v/out are [batch, N, heads*64] with row strides ldq/ldk/ldv/ldo (floats; batches are N*ld apart),

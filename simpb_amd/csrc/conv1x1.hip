@@ -1,0 +1,156 @@
+// 1x1 convolution of the fp16 channels_last backbone with its whole epilogue in one launch:
+//   y[p, :] = relu?( x[pixel(p), :] . W^T + bias (+ residual[p, :]) )        fp16 in / out, fp32 accumulate
+// 36 of the 53 convolutions of ResNet50 and the four FPN lateral convolutions are 1x1
+// (/root/reference/projects/configs/simpb_nus_r50_img_704x256.py:79-99: mmdet ResNet style="pytorch" + FPN).
+// After conv-BN folding (tools/fuse_conv_bn.py:10-48) each is a vendor convolution (12-30 us at 6 x 256 x 704)
+// followed by an in-place bias / residual / ReLU pass over the activation map (csrc/bias_act.hip, 3-20 us):
+// the map is written, read again with the residual and written again. These layers are bound by exactly that
+// traffic (0.1-2 GFLOP over 10-100 MB), so here the map is written once. (MIOpen's own fused
+// conv+bias+ReLU is 30-500x slower on these shapes: tools/bench_conv_fused.py.)
+//
+// One workgroup = 4 waves = 128 output pixels x 64 output channels, wave w owns pixels [32w, 32w+32) as two 32x32
+// tiles of v_mfma_f32_32x32x16_f16; K in chunks of 32 through LDS (rows of 64 B staged as 16-byte pieces, next
+// chunk in flight in registers, unconditional clamped loads). The accumulator tile goes through LDS once so that
+// the residual is read and y is written in 16-byte pieces of full 128-byte rows. `stride` (1 or 2) subsamples
+// the input pixels (the downsample branches of stages 2-4).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "../../include/simpb_hip.h"
+
+extern "C" int simpb_check_launch(void);
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int LDH = BK + 8;   // halfs per staged row (80 B): conflict-free 16-lane groups for ds_read_b128
+constexpr int LDC = BN + 1;   // floats per row of the epilogue tile
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restrict__ y, const _Float16* __restrict__ x,
+                                                               const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
+                                                               const _Float16* __restrict__ residual, int P_out, int Cin,
+                                                               int Cout, int relu, int stride, int Ho, int Wo, int H, int W) {
+  __shared__ _Float16 s_a[BM * LDH];
+  __shared__ _Float16 s_b[BN * LDH];
+  __shared__ float s_c[BM * LDC];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, kb = lane >> 5;
+  const int p0 = blockIdx.x * BM, c0 = blockIdx.y * BN;
+
+  // staging: a 16-byte piece = 8 halfs; A: 128 rows x 4 pieces -> 2 per thread, B: 64 rows x 4 -> 1 per thread
+  const int sr = tid >> 2, sc = (tid & 3) * 8;
+  size_t arow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int p = min(p0 + sr + 64 * i, P_out - 1);
+    if (stride != 1) {  // output pixel (n, ho, wo) reads input pixel (n, ho * stride, wo * stride)
+      const int n = p / (Ho * Wo), rem = p - n * (Ho * Wo);
+      const int ho = rem / Wo, wo = rem - ho * Wo;
+      p = (n * H + ho * stride) * W + wo * stride;
+    }
+    arow[i] = (size_t)p * Cin + sc;
+  }
+  const size_t brow = (size_t)min(c0 + sr, Cout - 1) * Cin + sc;
+  h16x8 pa[2], pb;
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+    pa[0] = *reinterpret_cast<const h16x8*>(x + arow[0] + k0);
+    pa[1] = *reinterpret_cast<const h16x8*>(x + arow[1] + k0);
+    pb = *reinterpret_cast<const h16x8*>(w + brow + k0);
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  fetch(0);
+  for (int k0 = 0; k0 < Cin; k0 += BK) {
+    __syncthreads();
+    *reinterpret_cast<h16x8*>(&s_a[sr * LDH + sc]) = pa[0];
+    *reinterpret_cast<h16x8*>(&s_a[(sr + 64) * LDH + sc]) = pa[1];
+    *reinterpret_cast<h16x8*>(&s_b[sr * LDH + sc]) = pb;
+    __syncthreads();
+    fetch(k0 + BK < Cin ? k0 + BK : k0);  // unconditional (the last iteration re-requests its own chunk)
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const h16x8 a = *reinterpret_cast<const h16x8*>(&s_a[(wave * 32 + r32) * LDH + 16 * ks + 8 * kb]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const h16x8 b = *reinterpret_cast<const h16x8*>(&s_b[(n * 32 + r32) * LDH + 16 * ks + 8 * kb]);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[n], 0, 0, 0);
+      }
+    }
+  }
+
+  // accumulators -> LDS (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_c[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb) * LDC + n * 32 + r32] = acc[n][r];
+  __syncthreads();
+  // epilogue in 16-byte pieces: 128 rows x 8 pieces -> 4 per thread
+  const bool full = c0 + BN <= Cout;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * kThreads;
+    const int r = idx >> 3, c8 = (idx & 7) * 8;
+    const int p = p0 + r;
+    if (p >= P_out) continue;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = s_c[r * LDC + c8 + e];
+    if (full) {
+      const h16x8 bv = *reinterpret_cast<const h16x8*>(bias + c0 + c8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)bv[e];
+      if (residual) {
+        const h16x8 rv = *reinterpret_cast<const h16x8*>(residual + (size_t)p * Cout + c0 + c8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+      }
+      h16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (_Float16)(relu ? fmaxf(v[e], 0.f) : v[e]);
+      *reinterpret_cast<h16x8*>(y + (size_t)p * Cout + c0 + c8) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + c8 + e;
+        if (c < Cout) {
+          float t = v[e] + (float)bias[c];
+          if (residual) t += (float)residual[(size_t)p * Cout + c];
+          y[(size_t)p * Cout + c] = (_Float16)(relu ? fmaxf(t, 0.f) : t);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const void* bias, const void* residual,
+                                      int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride,
+                                      int relu, void* stream) {
+  if (!y || !x || !weight || !bias || num_images <= 0 || in_h <= 0 || in_w <= 0 || in_channels <= 0 || out_channels <= 0 ||
+      (stride != 1 && stride != 2) || in_channels % BK != 0 || out_channels % 8 != 0)
+    return SIMPB_EINVAL;
+  if ((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(weight) |
+       reinterpret_cast<size_t>(bias) | reinterpret_cast<size_t>(residual)) & 15)
+    return SIMPB_EINVAL;
+  const int ho = (in_h - 1) / stride + 1, wo = (in_w - 1) / stride + 1;
+  const long long p_out = (long long)num_images * ho * wo;
+  if (p_out > (1ll << 30)) return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  dim3 grid((unsigned)((p_out + BM - 1) / BM), (out_channels + BN - 1) / BN);
+  if (grid.y > 65535) return SIMPB_EINVAL;
+  hipLaunchKernelGGL(conv1x1_f16_kernel, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     static_cast<_Float16*>(y), static_cast<const _Float16*>(x), static_cast<const _Float16*>(weight),
+                     static_cast<const _Float16*>(bias), static_cast<const _Float16*>(residual), (int)p_out, in_channels,
+                     out_channels, relu, stride, ho, wo, in_h, in_w);
+  return simpb_check_launch();
+}

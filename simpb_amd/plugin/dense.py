@@ -34,19 +34,19 @@ ENABLED = True
 # point tests of a stream fall within rounding distance of a border, and the golden vectors were matched
 # slot for slot with the exact kernels.
 SPLIT_FP16 = False
-_split_cache = {}
 
 
 def _split_weights(w):
-    """(w_hi, w_lo) f16 [N, K] of a contiguous f32 weight: w = w_hi + w_lo / 2048 up to ~2^-22 relative."""
-    key = (w.data_ptr(), tuple(w.shape), str(w.device))
-    hit = _split_cache.get(key)
-    if hit is None or hit[0] != w._version:
+    """(w_hi, w_lo) f16 [N, K] of a contiguous f32 weight: w = w_hi + w_lo / 2048 up to ~2^-22 relative. Cached ON
+    the tensor object (not in a table keyed by address or id(): both are reused once a model is freed)."""
+    tag = (w.data_ptr(), w._version, str(w.device))
+    hit = getattr(w, "_simpb_split", None)
+    if hit is None or hit[0] != tag:
         with torch.no_grad():
             hi = w.detach().half()
             lo = ((w.detach() - hi.float()) * 2048.0).half()
-        hit = (w._version, hi.contiguous(), lo.contiguous())
-        _split_cache[key] = hit
+        hit = (tag, hi.contiguous(), lo.contiguous())
+        w._simpb_split = hit
     return hit[1], hit[2]
 
 
@@ -243,18 +243,22 @@ def layernorm(xs, ln, out=None, m_live=None):
 
 # ---------------------------------------------------------------------------- weight folds
 class FoldCache:
-    """Derived weights keyed by the identity and version of the parameters they were built from."""
+    """Derived weights, stored ON the module that owns the leading parameter (`owner`) and tagged with the
+    address and version of every parameter they were built from. Not a global table keyed by id(): ids and
+    device addresses are reused once a model is freed, and a second model would pick up the first one's folds."""
 
-    def __init__(self):
-        self._store = {}
-
-    def get(self, key, params, build):
+    def get(self, key, params, build, owner=None):
         tag = tuple((p.data_ptr(), p._version, str(p.device)) if p is not None else None for p in params)
-        hit = self._store.get(key)
+        owner = owner if owner is not None else next(p for p in params if p is not None)
+        store = owner.__dict__.setdefault("_simpb_folds", {}) if hasattr(owner, "__dict__") else None
+        if store is None:
+            with torch.no_grad():
+                return build()
+        hit = store.get(key)
         if hit is None or hit[0] != tag:
             with torch.no_grad():
                 hit = (tag, build())
-            self._store[key] = hit
+            store[key] = hit
         return hit[1]
 
 
@@ -283,7 +287,7 @@ def fold_mha_in(attn, pre, mode):
         bias = {"qkv": b, "q": b[:e], "kv": b[e:]}[mode]
         return torch.cat(parts, 0).float().contiguous(), bias.detach().float().contiguous()
 
-    return _folds.get(("mha_in", id(attn), id(pre), mode), (w, b, pre.weight if pre is not None else None), build)
+    return _folds.get(("mha_in", mode, pre is not None), (w, b, pre.weight if pre is not None else None), build, owner=attn)
 
 
 def fold_mha_out(attn, post):
@@ -297,7 +301,7 @@ def fold_mha_out(attn, post):
         bias = (wa @ _f64(bo)).float().contiguous()
         return weight, bias
 
-    return _folds.get(("mha_out", id(attn), id(post)), (wo, bo, post.weight), build)
+    return _folds.get(("mha_out",), (wo, bo, post.weight), build, owner=attn)
 
 
 def fold_ffn_out(fc2, identity_fc):
@@ -308,8 +312,7 @@ def fold_ffn_out(fc2, identity_fc):
         bias = (fc2.bias.detach() + identity_fc.bias.detach()).float().contiguous()
         return weight, bias
 
-    return _folds.get(("ffn_out", id(fc2), id(identity_fc)),
-                      (fc2.weight, fc2.bias, identity_fc.weight, identity_fc.bias), build)
+    return _folds.get(("ffn_out",), (fc2.weight, fc2.bias, identity_fc.weight, identity_fc.bias), build, owner=fc2)
 
 
 def fold_split_last_column(lin):
@@ -320,7 +323,7 @@ def fold_split_last_column(lin):
         w = lin.weight.detach().float()
         return w[:, :-1].contiguous(), w[:, -1].contiguous()
 
-    return _folds.get(("split_last", id(lin)), (lin.weight,), build)
+    return _folds.get(("split_last",), (lin.weight,), build, owner=lin)
 
 
 def fold_sum_input(lin, copies=2):
@@ -329,7 +332,7 @@ def fold_sum_input(lin, copies=2):
     def build():
         return torch.cat([lin.weight.detach()] * copies, 1).float().contiguous()
 
-    return _folds.get(("sum_in", id(lin), copies), (lin.weight,), build)
+    return _folds.get(("sum_in", copies), (lin.weight,), build, owner=lin)
 
 
 def fold_stack(key, linears, copies=1):
@@ -342,4 +345,4 @@ def fold_stack(key, linears, copies=1):
         return weight, bias
 
     params = tuple(p for m in linears for p in (m.weight, m.bias))
-    return _folds.get((key, tuple(id(m) for m in linears), copies), params, build)
+    return _folds.get((key, copies, len(linears)), params, build, owner=linears[0])

@@ -17,6 +17,11 @@ from .registry import BACKBONES, DETECTORS, HEADS, NECKS, PLUGIN_LAYERS, build_f
 __all__ = ["SimPB", "ResNet", "FPN"]
 
 
+# True: conv1 / conv3 / downsample of the fp16 bottlenecks run as csrc/conv1x1.hip (one launch each, epilogue
+# included); False: vendor convolution + csrc/bias_act.hip (two launches), also the cross-check in tests.
+CONV1X1_KERNEL = True
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -44,18 +49,23 @@ class Bottleneck(nn.Module):
     def _forward_fused(self, x):
         """BN already folded (SimPB.fuse_conv_bn): convolutions run without bias and each is followed
         by ONE epilogue kernel (bias [+ residual] [+ ReLU]) instead of add_, add and relu_."""
-        from .ops import bias_act_
+        from .ops import bias_act_, conv1x1_nhwc
 
         def conv(m, t):
             return F.conv2d(t, m.weight, None, m.stride, m.padding)
 
-        if self.downsample is None:
-            identity = x
-        else:
-            identity = bias_act_(conv(self.downsample[0], x), self.downsample[0].bias, None, relu=False)
-        out = bias_act_(conv(self.conv1, x), self.conv1.bias, None, relu=True)
+        def pointwise(m, t, residual=None, relu=True):
+            # the 1x1 convolutions with their whole epilogue in one launch (csrc/conv1x1.hip); anything the kernel
+            # does not take (odd channel counts, an input that is not channels_last) goes the two-launch way
+            if (CONV1X1_KERNEL and m.in_channels % 32 == 0 and m.out_channels % 8 == 0 and m.stride[0] in (1, 2)
+                    and m.stride[0] == m.stride[1] and t.is_contiguous(memory_format=torch.channels_last)):
+                return conv1x1_nhwc(t, m.weight, m.bias, residual, relu, m.stride[0])
+            return bias_act_(conv(m, t), m.bias, residual, relu=relu)
+
+        identity = x if self.downsample is None else pointwise(self.downsample[0], x, None, relu=False)
+        out = pointwise(self.conv1, x)
         out = bias_act_(conv(self.conv2, out), self.conv2.bias, None, relu=True)
-        return bias_act_(conv(self.conv3, out), self.conv3.bias, identity, relu=True)
+        return pointwise(self.conv3, out, identity, relu=True)
 
 
 @BACKBONES.register_module()

@@ -330,6 +330,29 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
+def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1):
+    """relu?(conv1x1(x, weight, stride) + bias + residual?) for a channels_last f16 tensor, one launch
+    (csrc/conv1x1.hip). x [N, Cin, H, W]; weight [Cout, Cin, 1, 1] f16; bias f16 [Cout]."""
+    _require_gpu(x, weight, bias)
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    if (x.dtype != torch.float16 or not x.is_contiguous(memory_format=torch.channels_last) or weight.dtype != torch.float16
+            or bias.dtype != torch.float16 or weight.numel() != cout * cin or cin % 32 or cout % 8 or stride not in (1, 2)):
+        raise ValueError("conv1x1_nhwc takes channels_last f16 input, f16 [Cout, Cin, 1, 1] weight, Cin % 32 == 0, Cout % 8 == 0")
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float16, memory_format=torch.channels_last)
+    if residual is not None and (residual.shape != y.shape or residual.dtype != torch.float16
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError("residual must match the output (channels_last f16)")
+    w2 = weight.reshape(cout, cin)
+    if not w2.is_contiguous():
+        w2 = w2.contiguous()
+    status = _lib.lib().simpb_conv1x1_nhwc_f16(_ptr(y), _ptr(x), _ptr(w2), _ptr(bias), _ptr(residual) if residual is not None else None,
+                                               n, h, w, cin, cout, stride, 1 if relu else 0, _stream())
+    _lib.check(status, "simpb_conv1x1_nhwc_f16")
+    return y
+
+
 def topk_rows(scores, k):
     """(values [bs, k] sorted descending, indices i64 [bs, k]) of scores f32 [bs, n]: torch.topk(sorted=True)
     semantics with ties broken towards the lower index, one launch (csrc/rowops.hip)."""
@@ -346,7 +369,6 @@ def topk_rows(scores, k):
     return values, index.long()
 
 
-_split_cache = {}
 
 
 def linear_split(x, weight, bias=None):
@@ -358,14 +380,14 @@ def linear_split(x, weight, bias=None):
     if weight.shape[1] != k or k % 32:
         raise ValueError("linear_split: x [..., K], weight [N, K], K a multiple of 32")
     tag = (weight.data_ptr(), weight._version, str(weight.device))
-    hit = _split_cache.get(id(weight))
+    hit = getattr(weight, "_simpb_split_lin", None)  # cached on the tensor object: ids / addresses get reused
     if hit is None or hit[0] != tag:
         with torch.no_grad():
             w = weight.detach().float()
             hi = w.half()
             lo = ((w - hi.float()) * 2048.0).half()
         hit = (tag, hi.contiguous(), lo.contiguous())
-        _split_cache[id(weight)] = hit
+        weight._simpb_split_lin = hit
     x2 = x.contiguous().float().reshape(-1, k)
     m, n = x2.shape[0], weight.shape[0]
     y = torch.empty(m, n, device=x.device, dtype=torch.float32)

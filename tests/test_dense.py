@@ -444,3 +444,32 @@ def test_linear_split_fp16_passes_reach_fp32_accuracy(m, scale):
     assert float((got.double() - want).abs().max()) <= bound
     # and no worse than 4x the exact kernel's own rounding error
     assert float((got.double() - want).abs().max()) <= 4 * float((exact.double() - want).abs().max()) + 1e-7 * scale
+
+
+@gpu
+@pytest.mark.parametrize("cin,cout,h,w,stride,res,relu", [
+    (64, 256, 64, 176, 1, True, True),      # layer1 conv3 + residual
+    (256, 64, 64, 176, 1, False, True),     # layer1 conv1
+    (256, 512, 64, 176, 2, False, False),   # layer2 downsample, stride 2
+    (2048, 512, 8, 22, 1, False, True),     # layer4 conv1, small map
+    (96, 40, 5, 7, 2, True, True),          # ragged pixels / channels, odd sizes with stride 2
+])
+def test_conv1x1_kernel_vs_conv2d(cin, cout, h, w, stride, res, relu):
+    """csrc/conv1x1.hip against F.conv2d + bias (+ residual) (+ ReLU) evaluated in fp32 on the same fp16 values:
+    the kernel accumulates in fp32 and rounds once, so it must sit within one fp16 rounding of that reference."""
+    from simpb_amd.plugin.ops import conv1x1_nhwc
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(3, cin, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).half().cuda()
+    b = torch.randn(cout, generator=g).half().cuda()
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    r = torch.randn(3, cout, ho, wo, generator=g).half().cuda().contiguous(memory_format=torch.channels_last) if res else None
+    want = F.conv2d(x.float(), wt.float(), b.float(), stride=stride)
+    if res:
+        want = want + r.float()
+    if relu:
+        want = want.relu()
+    got = conv1x1_nhwc(x, wt, b, r, relu, stride)
+    assert got.shape == want.shape and got.dtype == torch.float16 and got.is_contiguous(memory_format=torch.channels_last)
+    err = (got.float() - want).abs()
+    assert float((err - 1e-3 * want.abs()).max()) <= 2e-3   # fp16 output rounding: 2^-11 relative + small absolute

@@ -83,6 +83,7 @@ def test_pipelined_runner_vs_golden():
             super().__init__()
             self.head = head
             self.bufs = {}
+            self.staged = None
 
         def extract_feat(self, img):
             # the "image" carries the frame index; features are the golden stream's synthetic maps,
@@ -102,7 +103,12 @@ def test_pipelined_runner_vs_golden():
     from simpb_amd.plugin import ops
     outs = []
     for f in range(spec["frames"]):
-        model.staged = ops.feature_maps_format([x.cuda() for x in synth.feature_maps_nchw(1, f, spec["image_wh"])])[0]
+        # one persistent staging buffer: extract_feat's copy may be replayed from a captured graph, which
+        # bakes in the source address (a fresh tensor per frame made this test depend on allocator reuse)
+        fresh = ops.feature_maps_format([x.cuda() for x in synth.feature_maps_nchw(1, f, spec["image_wh"])])[0]
+        if getattr(model, "staged", None) is None:
+            model.staged = torch.empty_like(fresh)
+        model.staged.copy_(fresh)
         torch.cuda.synchronize()
         outs.append(runner.step(runner.img, synth.frame_metas(1, f, spec["image_wh"])))
     outs.append(runner.flush())
