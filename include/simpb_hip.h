@@ -178,7 +178,7 @@ int simpb_bias_act_nhwc_f16(void* y, const void* bias, const void* residual, lon
  *   y[n, ho, wo, :] = relu?( x[n, ho*stride, wo*stride, :] . weight^T + bias (+ residual[n, ho, wo, :]) )
  * x f16 [num_images, in_h, in_w, in_channels] (NHWC), weight f16 [out_channels, in_channels], bias f16 [out_channels],
  * residual f16 like y or NULL, y f16 [num_images, ho, wo, out_channels] with ho = (in_h - 1) / stride + 1; fp32
- * accumulate. stride 1 or 2; in_channels % 32 == 0, out_channels % 8 == 0; 16-byte aligned. These are conv1 / conv3 /
+ * accumulate. stride 1 or 2; in_channels % 64 == 0, out_channels % 8 == 0; 16-byte aligned. These are conv1 / conv3 /
  * downsample of every ResNet bottleneck and the FPN lateral convolutions (mmdet ResNet + FPN of
  * projects/configs/simpb_nus_r50_img_704x256.py:79-99 after tools/fuse_conv_bn.py:10-48). */
 int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const void* bias, const void* residual,

@@ -9,12 +9,13 @@
 // conv+bias+ReLU is 30-500x slower on these shapes: tools/bench_conv_fused.py.)
 //
 // One workgroup = 4 waves = 128 output pixels x 64 output channels, wave w owns pixels [32w, 32w+32) as two 32x32
-// tiles of v_mfma_f32_32x32x16_f16; K in chunks of 32 through LDS (rows of 64 B staged as 16-byte pieces, next
-// chunk in flight in registers, unconditional clamped loads). The accumulator tile goes through LDS once so that
+// tiles of v_mfma_f32_32x32x16_f16; K in chunks of 64 through LDS (rows of 128 B staged as 16-byte pieces, two
+// chunks in flight in registers, unconditional clamped loads). The accumulator tile goes through LDS once so that
 // the residual is read and y is written in 16-byte pieces of full 128-byte rows. `stride` (1 or 2) subsamples
 // the input pixels (the downsample branches of stages 2-4).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <type_traits>
 #include "../../include/simpb_hip.h"
 
 extern "C" int simpb_check_launch(void);
@@ -24,8 +25,8 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
-constexpr int BM = 128, BN = 64, BK = 32;
-constexpr int LDH = BK + 8;   // halfs per staged row (80 B): conflict-free 16-lane groups for ds_read_b128
+constexpr int BM = 128, BN = 64, BK = 64;
+constexpr int LDH = BK + 8;   // halfs per staged row (144 B): conflict-free 16-lane groups for ds_read_b128
 constexpr int LDC = BN + 1;   // floats per row of the epilogue tile
 constexpr int kThreads = 256;
 
@@ -33,20 +34,25 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
                                                                const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                                                                const _Float16* __restrict__ residual, int P_out, int Cin,
                                                                int Cout, int relu, int stride, int Ho, int Wo, int H, int W) {
-  __shared__ _Float16 s_a[BM * LDH];
-  __shared__ _Float16 s_b[BN * LDH];
-  __shared__ float s_c[BM * LDC];
+  // the epilogue tile reuses the staging memory (33 KB per workgroup instead of 61: four workgroups per CU)
+  constexpr int kStageBytes = (BM + BN) * LDH * 2, kTileBytes = BM * LDC * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kStageBytes > kTileBytes ? kStageBytes : kTileBytes];
+  _Float16* s_a = reinterpret_cast<_Float16*>(smem);
+  _Float16* s_b = s_a + BM * LDH;
+  float* s_c = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, kb = lane >> 5;
   const int p0 = blockIdx.x * BM, c0 = blockIdx.y * BN;
 
-  // staging: a 16-byte piece = 8 halfs; A: 128 rows x 4 pieces -> 2 per thread, B: 64 rows x 4 -> 1 per thread
-  const int sr = tid >> 2, sc = (tid & 3) * 8;
-  size_t arow[2];
+  // staging: a 16-byte piece = 8 halfs; a chunk row has BK/8 = 8 pieces; A: 128 rows -> 4 pieces per thread,
+  // B: 64 rows -> 2 per thread. Two register sets of chunks in flight, unconditional clamped loads.
+  constexpr int C8 = BK / 8, RS = kThreads / C8, NA = BM / RS, NB = BN / RS;
+  const int sr = tid / C8, sc = (tid % C8) * 8;
+  size_t arow[NA], brow[NB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int p = min(p0 + sr + 64 * i, P_out - 1);
+  for (int i = 0; i < NA; ++i) {
+    int p = min(p0 + sr + RS * i, P_out - 1);
     if (stride != 1) {  // output pixel (n, ho, wo) reads input pixel (n, ho * stride, wo * stride)
       const int n = p / (Ho * Wo), rem = p - n * (Ho * Wo);
       const int ho = rem / Wo, wo = rem - ho * Wo;
@@ -54,12 +60,24 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
     }
     arow[i] = (size_t)p * Cin + sc;
   }
-  const size_t brow = (size_t)min(c0 + sr, Cout - 1) * Cin + sc;
-  h16x8 pa[2], pb;
-  auto fetch = [&](int k0) __attribute__((always_inline)) {
-    pa[0] = *reinterpret_cast<const h16x8*>(x + arow[0] + k0);
-    pa[1] = *reinterpret_cast<const h16x8*>(x + arow[1] + k0);
-    pb = *reinterpret_cast<const h16x8*>(w + brow + k0);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) brow[i] = (size_t)min(c0 + sr + RS * i, Cout - 1) * Cin + sc;
+  const int nchunks = Cin / BK;
+  h16x8 pa[2][NA], pb[2][NB];
+  auto fetch = [&](auto set_c, int chunk) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    const int k0 = min(chunk, nchunks - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) pa[set][i] = *reinterpret_cast<const h16x8*>(x + arow[i] + k0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) pb[set][i] = *reinterpret_cast<const h16x8*>(w + brow[i] + k0);
+  };
+  auto stash = [&](auto set_c, int) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<h16x8*>(&s_a[(sr + RS * i) * LDH + sc]) = pa[set][i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<h16x8*>(&s_b[(sr + RS * i) * LDH + sc]) = pb[set][i];
   };
 
   f32x16 acc[2];
@@ -68,14 +86,7 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-  fetch(0);
-  for (int k0 = 0; k0 < Cin; k0 += BK) {
-    __syncthreads();
-    *reinterpret_cast<h16x8*>(&s_a[sr * LDH + sc]) = pa[0];
-    *reinterpret_cast<h16x8*>(&s_a[(sr + 64) * LDH + sc]) = pa[1];
-    *reinterpret_cast<h16x8*>(&s_b[sr * LDH + sc]) = pb;
-    __syncthreads();
-    fetch(k0 + BK < Cin ? k0 + BK : k0);  // unconditional (the last iteration re-requests its own chunk)
+  auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const h16x8 a = *reinterpret_cast<const h16x8*>(&s_a[(wave * 32 + r32) * LDH + 16 * ks + 8 * kb]);
@@ -85,9 +96,27 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[n], 0, 0, 0);
       }
     }
+  };
+
+  fetch(std::integral_constant<int, 0>{}, 0);
+  fetch(std::integral_constant<int, 1>{}, 1);
+  for (int c = 0; c < nchunks; c += 2) {
+    __syncthreads();
+    stash(std::integral_constant<int, 0>{}, c);
+    __syncthreads();
+    fetch(std::integral_constant<int, 0>{}, c + 2);
+    multiply();
+    if (c + 1 < nchunks) {
+      __syncthreads();
+      stash(std::integral_constant<int, 1>{}, c + 1);
+      __syncthreads();
+      fetch(std::integral_constant<int, 1>{}, c + 3);
+      multiply();
+    }
   }
 
   // accumulators -> LDS (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+  __syncthreads();  // every wave is done reading the last staged chunk
 #pragma unroll
   for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -137,7 +166,7 @@ extern "C" int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight
                                       int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride,
                                       int relu, void* stream) {
   if (!y || !x || !weight || !bias || num_images <= 0 || in_h <= 0 || in_w <= 0 || in_channels <= 0 || out_channels <= 0 ||
-      (stride != 1 && stride != 2) || in_channels % BK != 0 || out_channels % 8 != 0)
+      (stride != 1 && stride != 2) || in_channels % BK != 0 || out_channels % 8 != 0)  // BK = 64
     return SIMPB_EINVAL;
   if ((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(weight) |
        reinterpret_cast<size_t>(bias) | reinterpret_cast<size_t>(residual)) & 15)

@@ -57,7 +57,7 @@ class Bottleneck(nn.Module):
         def pointwise(m, t, residual=None, relu=True):
             # the 1x1 convolutions with their whole epilogue in one launch (csrc/conv1x1.hip); anything the kernel
             # does not take (odd channel counts, an input that is not channels_last) goes the two-launch way
-            if (CONV1X1_KERNEL and m.in_channels % 32 == 0 and m.out_channels % 8 == 0 and m.stride[0] in (1, 2)
+            if (CONV1X1_KERNEL and m.in_channels % 64 == 0 and m.out_channels % 8 == 0 and m.stride[0] in (1, 2)
                     and m.stride[0] == m.stride[1] and t.is_contiguous(memory_format=torch.channels_last)):
                 return conv1x1_nhwc(t, m.weight, m.bias, residual, relu, m.stride[0])
             return bias_act_(conv(m, t), m.bias, residual, relu=relu)

@@ -337,8 +337,8 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1):
     n, cin, h, w = x.shape
     cout = weight.shape[0]
     if (x.dtype != torch.float16 or not x.is_contiguous(memory_format=torch.channels_last) or weight.dtype != torch.float16
-            or bias.dtype != torch.float16 or weight.numel() != cout * cin or cin % 32 or cout % 8 or stride not in (1, 2)):
-        raise ValueError("conv1x1_nhwc takes channels_last f16 input, f16 [Cout, Cin, 1, 1] weight, Cin % 32 == 0, Cout % 8 == 0")
+            or bias.dtype != torch.float16 or weight.numel() != cout * cin or cin % 64 or cout % 8 or stride not in (1, 2)):
+        raise ValueError("conv1x1_nhwc takes channels_last f16 input, f16 [Cout, Cin, 1, 1] weight, Cin % 64 == 0, Cout % 8 == 0")
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     y = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float16, memory_format=torch.channels_last)
     if residual is not None and (residual.shape != y.shape or residual.dtype != torch.float16

@@ -452,7 +452,7 @@ def test_linear_split_fp16_passes_reach_fp32_accuracy(m, scale):
     (256, 64, 64, 176, 1, False, True),     # layer1 conv1
     (256, 512, 64, 176, 2, False, False),   # layer2 downsample, stride 2
     (2048, 512, 8, 22, 1, False, True),     # layer4 conv1, small map
-    (96, 40, 5, 7, 2, True, True),          # ragged pixels / channels, odd sizes with stride 2
+    (192, 40, 5, 7, 2, True, True),         # ragged pixels / channels, odd sizes with stride 2, 3 K chunks
 ])
 def test_conv1x1_kernel_vs_conv2d(cin, cout, h, w, stride, res, relu):
     """csrc/conv1x1.hip against F.conv2d + bias (+ residual) (+ ReLU) evaluated in fp32 on the same fp16 values:
