@@ -151,6 +151,22 @@ class FPN(BaseModule):
             self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1))
 
     def forward(self, inputs):
+        x0 = inputs[self.start_level]
+        if (CONV1X1_KERNEL and x0.is_cuda and x0.dtype == torch.float16 and self.upsample_cfg.get("mode") == "nearest"
+                and all(t.is_contiguous(memory_format=torch.channels_last) for t in inputs)
+                and all(m.conv.in_channels % 64 == 0 and m.conv.out_channels % 8 == 0 for m in self.lateral_convs)):
+            # lateral 1x1 convolutions as csrc/conv1x1.hip launches, the top-down sum riding along as the residual:
+            # lateral[i-1] = conv(c[i-1]) + up(lateral[i])  (mmdet FPN.forward), coarsest level first
+            from .ops import conv1x1_nhwc
+            n = len(self.lateral_convs)
+            laterals = [None] * n
+            for i in range(n - 1, -1, -1):
+                conv = self.lateral_convs[i].conv
+                up = None
+                if i < n - 1:
+                    up = F.interpolate(laterals[i + 1], size=inputs[i + self.start_level].shape[2:], **self.upsample_cfg)
+                laterals[i] = conv1x1_nhwc(inputs[i + self.start_level], conv.weight, conv.bias, up, relu=False)
+            return tuple(self.fpn_convs[i](laterals[i]) for i in range(n))
         laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
         for i in range(len(laterals) - 1, 0, -1):
             laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
