@@ -98,6 +98,19 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
     }
   };
 
+  // the residual pieces this thread will add in the epilogue are requested first, so that their round trip
+  // is over by the time the (short: Cin / 64 chunks) K loop ends
+  const bool full = c0 + BN <= Cout;
+  h16x8 rres[4];
+  if (residual && full) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * kThreads;
+      const int p = min(p0 + (idx >> 3), P_out - 1);
+      rres[i] = *reinterpret_cast<const h16x8*>(residual + (size_t)p * Cout + c0 + (idx & 7) * 8);
+    }
+  }
+
   fetch(std::integral_constant<int, 0>{}, 0);
   fetch(std::integral_constant<int, 1>{}, 1);
   for (int c = 0; c < nchunks; c += 2) {
@@ -123,7 +136,6 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
     for (int r = 0; r < 16; ++r) s_c[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb) * LDC + n * 32 + r32] = acc[n][r];
   __syncthreads();
   // epilogue in 16-byte pieces: 128 rows x 8 pieces -> 4 per thread
-  const bool full = c0 + BN <= Cout;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + i * kThreads;
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)bv[e];
       if (residual) {
-        const h16x8 rv = *reinterpret_cast<const h16x8*>(residual + (size_t)p * Cout + c0 + c8);
+        const h16x8 rv = rres[i];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
       }
