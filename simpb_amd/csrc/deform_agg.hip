@@ -198,7 +198,7 @@ extern "C" int simpb_deformable_aggregation_forward(
   return simpb_check_launch();
 }
 
-extern "C" int simpb_abi_version(void) { return 1; }
+extern "C" int simpb_abi_version(void) { return 2; }  // 2: simpb_mlp_chain gained the post stage (8 chains per launch)
 
 // ---- optional per-launch HIP-event timing (bench.py's roofline leg). Events are recorded on the
 // launch stream immediately around the kernel launch, inside the same C call, so the interval
