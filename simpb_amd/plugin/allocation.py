@@ -110,6 +110,10 @@ class DynamicQueryAllocation(nn.Module):
                                            _ptr(order), _ptr(flag), _ptr(sel_xy), _ptr(depth), bs, num_anchor, cams, n2,
                                            img_w, img_h, st), "simpb_alloc_scatter")
         self.last = out
+        if capacity is not None:
+            # static mode: the mask / count views of the reference's tuple (allocation.py:144) are only consumed by
+            # the variable-shape decode; the static decode works from `out`, so they are not materialised
+            return out, ref_pts2d, ref_depth2d, None, None
         trans_mask = (flag != 0).permute(0, 2, 1)
         return out, ref_pts2d, ref_depth2d, trans_mask, count.long()
 
