@@ -319,7 +319,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"simpb_nus_r{args.depth}_img_{args.image_wh[0]}x{args.image_wh[1]}: 6-cam frames, "
                                    f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, {args.streams} stream(s) x bs={args.bs} per GPU, temporal",
-                       "streams_per_gpu": args.bs * args.streams, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
+                       "streams_per_gpu": args.bs * args.streams, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "head_dtype": "f32 throughout; value_proj on the FP16 matrix cores with split operands and f32 accumulators (fp32-grade: same 2e-5 bound vs float64 as the exact kernel)", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
                        if world > 1 else "single GPU", "num_query2d_last_frame": n2, "frame_runner": mode},
             "roofline": roof, "roofline_msda": roof2,
         }
