@@ -230,12 +230,8 @@ class SimPBHead(BaseModule):
         instance_feature, anchor, temp_instance_feature, temp_anchor, time_interval = self.instance_bank.get(
             batch_size, metas, dn_metas=None)
         if temp_anchor is not None and anchor.is_cuda:
-            # one encoder launch over both anchor sets (the chain kernel is latency-bound per launch); the bank
-            # may already hold them back to back (instance_bank.py:_both_anchors)
-            both_in = getattr(self.instance_bank, "both_anchor", None)
-            if both_in is None or both_in.shape[1] != anchor.shape[1] + temp_anchor.shape[1] or both_in.shape[0] != batch_size:
-                both_in = torch.cat([anchor, temp_anchor], dim=1)
-            both = self.anchor_encoder.forward(both_in)
+            # one encoder launch over both anchor sets (the chain kernel is latency-bound per launch)
+            both = self.anchor_encoder.forward(torch.cat([anchor, temp_anchor], dim=1))
             anchor_embed = dense.report(self.anchor_encoder, both[:, : anchor.shape[1]])
             temp_anchor_embed = dense.report(self.anchor_encoder, both[:, anchor.shape[1]:])
         else:

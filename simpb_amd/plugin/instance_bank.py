@@ -80,7 +80,7 @@ class InstanceBank(nn.Module):
         for name in _STATE_FIELDS:
             setattr(self, name, None)
         self.prev_id = 0
-        self.metas = self.mask = self.temp_confidence = self._kept_index = self.both_anchor = None
+        self.metas = self.mask = self.temp_confidence = self._kept_index = None
         self.has_history = False
         if self._static is not None:
             self._static["instance_id"].fill_(-1)
@@ -143,11 +143,7 @@ class InstanceBank(nn.Module):
             stored = self._static["cached_anchor"]
             self.cached_feature = self._static["cached_feature"]
             bs, t = stored.shape[:2]
-            # bs = 1: the warped anchors land behind the learned ones in one persistent [1, A + T, 11] buffer, which
-            # is what the anchor encoder embeds in one launch (the head would otherwise `cat` the two sets)
-            both = self._both_anchors(stored) if bs == 1 else None
-            warped = both[:, self.num_anchor:] if both is not None else torch.empty_like(stored)
-            self.both_anchor = both
+            warped = torch.empty_like(stored)
             self.mask = torch.empty(bs, dtype=torch.bool, device=stored.device)
             dt_out = torch.empty(bs, dtype=torch.float32, device=stored.device)
             lib = _lib.lib()
@@ -229,20 +225,6 @@ class InstanceBank(nn.Module):
         self._keep("cached_feature", kept_feature)
         self._keep("cached_anchor", kept_anchor)
         self.has_history = True
-
-    def _both_anchors(self, like):
-        """Persistent [1, A + T, 11]: rows [0, A) = the learned anchors (refreshed when the parameter changes),
-        rows [A, A + T) = scratch for the warped cached anchors of the current frame."""
-        tag = (self.anchor.data_ptr(), self.anchor._version)
-        buf = self._static.get("anchor_both")
-        if buf is None or buf.device != like.device:
-            buf = torch.empty(1, self.num_anchor + self.num_temp_instances, self.anchor.shape[-1], device=like.device)
-            self._static["anchor_both"] = buf
-            self._static["anchor_both_tag"] = None
-        if self._static.get("anchor_both_tag") != tag:
-            buf[:, : self.num_anchor].copy_(self.anchor.detach())
-            self._static["anchor_both_tag"] = tag
-        return buf
 
     def _fusable(self, t):
         return (FUSED_BANK and self._static is not None and t.is_cuda and self.anchor.shape[-1] == 11

@@ -135,6 +135,12 @@ class PipelinedRunner(FrameRunner):
     last frame). Two feature buffers alternate; each (backbone, decoder) x (buffer) pair is its own
     hipGraph once warm, so the steady state is two graph launches per step."""
 
+    # Eager (not yet captured) decoder work beside eager or replayed backbone work on the other stream gave wrong
+    # detections in about one run of six on MI355X (tools/pipe_race.py --eager: bit-exact otherwise, garbage
+    # from the first warm frame on when it hits), while two replayed graphs side by side, or everything on one
+    # stream, are bit-exact. Until the cause is pinned down the few eager steps of a stream are serialised.
+    SERIALIZE_EAGER = True
+
     def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True):
         super().__init__(model, batch_size, image_hw, capacity, device, use_graph)
         dev = self.device
@@ -261,6 +267,11 @@ class PipelinedRunner(FrameRunner):
             pslot, pmetas = self.pending
             self._stage_head_inputs(pmetas)
             warm = self.prev_metas is not None
+            if self.SERIALIZE_EAGER and not (self.fm[slot] is self.bb_out[slot] and self.head_graph[pslot] is not None
+                                             and not force_eager and warm):
+                # warm-up steps (either side still eager, or about to be captured) run one after the other: only
+                # replayed graphs overlap. See SERIALIZE_EAGER above.
+                self.s_head.wait_stream(self.s_bb)
             rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"], warm, force_eager)
             self._enqueue_readback(rec)
             self._inflight = pmetas

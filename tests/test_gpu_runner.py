@@ -117,12 +117,35 @@ def test_pipelined_runner_vs_golden():
         compare_result(outs[f + 1][0]["img_bbox"], g, f"f{f}.res0.")
 
 
+class _ReplayModel(torch.nn.Module):
+    """Detector stand-in that serves recorded feature maps from fixed-address buffers."""
+
+    def __init__(self, head):
+        super().__init__()
+        self.head = head
+        self.maps = None
+
+    def load(self, fm):
+        if self.maps is None:
+            self.maps = [t.clone() for t in fm]
+        else:
+            for dst, src in zip(self.maps, fm):
+                dst.copy_(src)
+
+    def extract_feat(self, img):
+        return self.maps
+
+
 def test_pipelined_equals_plain_runner_with_real_backbone():
-    """Whole detector (ResNet50+FPN with folded BN, kept in fp32 here so that runs are comparable to
-    1e-3: fp16 convolutions differ run to run by more than that once random-weight heads amplify
-    them) + decoder, 12 frames: the pipelined runner
-    (two streams, four graphs) returns what the plain graph runner returns, one step later, and the
-    plain graph runner returns what the eager static path returns."""
+    """Whole detector (ResNet50+FPN with folded BN + decoder), 12 frames, through the graph runner and the
+    pipelined runner (two streams, four graphs, backbone(t+1) beside decoder(t)).
+
+    The vendor's convolutions are not bit-reproducible from one run to the next (tools/pipe_determinism.py:
+    the feature maps of two EAGER runs already differ in every frame), and a 1e-7 difference that flips one
+    inside/outside test of the query allocation moves scores by 1e-2 for the rest of the stream, so two runs
+    of the detector cannot be compared to 1e-3. Instead each runner's features are recorded as its decoder
+    saw them and served again to the plain eager runner: a stale slot, a decoder that started before its
+    backbone finished or a backbone that overwrote maps still in use would all show as a difference."""
     from simpb_amd import configs, plugin
     from simpb_amd.runner import FrameRunner, PipelinedRunner
     wh = (352, 128)
@@ -136,23 +159,46 @@ def test_pipelined_equals_plain_runner_with_real_backbone():
     frames = 12
     imgs = [synth.images(1, f % 4, wh).cuda() for f in range(frames)]
     metas = [synth.frame_metas(1, f, wh) for f in range(frames)]
-    runs = {}
-    for name, cls, graph in (("eager", FrameRunner, False), ("graph", FrameRunner, True), ("pipe", PipelinedRunner, True)):
-        r = cls(make(), 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=graph)
-        out = [r.step(imgs[f], metas[f]) for f in range(frames)]
+
+    def snapshot(fm):
+        return [t.clone() for t in list(fm)[:3]]
+
+    for name in ("graph", "pipe"):
+        model = make()
+        seen = []
         if name == "pipe":
+            r = PipelinedRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=True)
+            out = []
+            for f in range(frames):
+                out.append(r.step(imgs[f], metas[f]))
+                if f >= 1:  # the maps decoder(f-1) just read; backbone(f) wrote the other slot meanwhile
+                    seen.append(snapshot(r.fm[(f - 1) % 2]))
+            seen.append(snapshot(r.fm[(frames - 1) % 2]))
             out = out[1:] + [r.flush()]
             assert r.stats["replay"] >= 4, r.stats
-        runs[name] = out
-    for f in range(frames):
-        a = runs["eager"][f][0]["img_bbox"]
-        for other in ("graph", "pipe"):
-            b = runs[other][f][0]["img_bbox"]
+        else:
+            r = FrameRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=True)
+            inner, last = model.extract_feat, {}
+
+            def spy(img):
+                last["fm"] = inner(img)
+                return last["fm"]
+
+            model.extract_feat = spy
+            out = []
+            for f in range(frames):
+                out.append(r.step(imgs[f], metas[f]))
+                seen.append(snapshot(last["fm"]))
+            assert r.stats["replay"] >= 4, r.stats
+        replay = _ReplayModel(make().head)
+        plain = FrameRunner(replay, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=False)
+        for f in range(frames):
+            replay.load(seen[f])
+            a = plain.step(plain.img, metas[f])[0]["img_bbox"]
+            b = out[f][0]["img_bbox"]
             assert a["boxes_3d"].shape == b["boxes_3d"].shape
-            # 2e-3 like the boxes below: the vendor's fp32 convolutions are not bit-reproducible between an eager and a
-            # replayed / overlapped run, and the random-weight head amplifies that to ~1e-3 on a few scores (seen: 1.14e-3)
-            assert float((a["scores_3d"] - b["scores_3d"]).abs().max()) <= 2e-3, (other, f)
-            assert rows_match_t(a["boxes_3d"], b["boxes_3d"], 2e-3), (other, f)
+            assert float((a["scores_3d"] - b["scores_3d"]).abs().max()) <= 1e-3, (name, f)
+            assert rows_match_t(a["boxes_3d"], b["boxes_3d"], 1e-3), (name, f)
 
 
 def rows_match_t(a, b, tol):
