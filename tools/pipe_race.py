@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--no-serialize", action="store_true", help="PipelinedRunner.SERIALIZE_EAGER = False")
     ap.add_argument("--dummy-backbone", action="store_true",
                     help="backbone stream runs big matmuls + a copy of pre-computed features instead of the convolutions")
+    ap.add_argument("--no-miopen", action="store_true", help="torch.backends.cudnn.enabled = False: PyTorch's own convolutions")
     ap.add_argument("--trace", type=int, default=-1, help="frame whose decoder inputs / per-layer outputs are compared")
     args = ap.parse_args()
     from simpb_amd import configs, plugin, synth
@@ -37,6 +38,8 @@ def main():
     dev = torch.device("cuda")
     if args.no_serialize:
         PipelinedRunner.SERIALIZE_EAGER = False
+    if args.no_miopen:
+        torch.backends.cudnn.enabled = False
     if args.load:
         junk = [torch.full((n,), float("nan"), device=dev) for n in (1 << 20, 1 << 22, 1 << 24, 3 << 20, 5 << 18) for _ in range(8)]
         del junk
@@ -89,6 +92,21 @@ def main():
         for name, mod in head.named_modules():
             if name:
                 mod.register_forward_hook(hook_for(name))
+
+        inner_get = bank.get
+
+        def spy_get(*a, **k):
+            if cur["rec"] is not None and k.get("dn_metas") is None and len(a) >= 2 and "bank_inputs" in a[1]:
+                flat("bank_get.in.T_dt", list(a[1]["bank_inputs"]), cur["rec"])
+                st2 = getattr(bank, "_static", None) or {}
+                if "cached_anchor" in st2:
+                    flat("bank_get.in.stored", st2["cached_anchor"], cur["rec"])
+            res = inner_get(*a, **k)
+            if cur["rec"] is not None:
+                flat("bank_get.out", [x for x in res], cur["rec"])
+            return res
+
+        bank.get = spy_get
 
         def forward(fm, metas, *a, **k):
             rec = {}
@@ -164,7 +182,7 @@ def main():
             for key in a:
                 if key in b and a[key].shape == b[key].shape:
                     d = float((a[key].double() - b[key].double()).abs().max()) if a[key].numel() else 0.0
-                    if d != 0.0 or key.startswith("in."):
+                    if d != 0.0 or key.startswith("in.") or key.startswith("bank_get"):
                         print(f"    trace frame {args.trace} {key:40s} max|pipe - plain| = {d:.3e}  max|pipe| = {float(a[key].double().abs().max()) if a[key].numel() else 0:.3e}")
                 else:
                     print(f"    trace frame {args.trace} {key:40s} only in pipe or shape differs")
