@@ -71,44 +71,53 @@ def test_runner_overflow_is_loud():
         runner.step(runner.img, synth.frame_metas(spec["bs"], 0, spec["image_wh"]))
 
 
-def test_pipelined_runner_vs_golden():
-    """Backbone(t+1) overlapped with decoder(t): same detections, one step later."""
+class _StagedModel(torch.nn.Module):
+    """Detector stand-in for the pipelined runner: the "image" is ignored, features are the golden stream's
+    synthetic maps, copied from one persistent staging buffer (a captured backbone graph bakes in the source
+    address) into a per-slot buffer so that the captured graphs stay valid."""
+
+    def __init__(self, head, spec):
+        super().__init__()
+        self.head = head
+        self.spec = spec
+        self.bufs = {}
+        self.staged = None
+
+    def stage(self, f):
+        from simpb_amd.plugin import ops
+        fresh = ops.feature_maps_format([x.cuda() for x in synth.feature_maps_nchw(1, f, self.spec["image_wh"])])[0]
+        if self.staged is None:
+            self.staged = torch.empty_like(fresh)
+        self.staged.copy_(fresh)
+
+    def extract_feat(self, img):
+        from simpb_amd.plugin import ops
+        key = img.data_ptr()
+        if key not in self.bufs:
+            self.bufs[key] = ops.feature_maps_format(
+                [torch.zeros_like(x).cuda() for x in synth.feature_maps_nchw(1, 0, self.spec["image_wh"])])
+        self.bufs[key][0].copy_(self.staged, non_blocking=True)
+        return self.bufs[key]
+
+
+def _golden_pipelined_runner(spec):
     from simpb_amd.runner import PipelinedRunner
-    g = load_golden("head_r50.npz")
-    spec = spec_of(g)
-    head = build_product_head(spec)
-
-    class Model(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.head = head
-            self.bufs = {}
-            self.staged = None
-
-        def extract_feat(self, img):
-            # the "image" carries the frame index; features are the golden stream's synthetic maps,
-            # written into a per-slot buffer so that a captured backbone graph stays valid
-            from simpb_amd.plugin import ops
-            key = img.data_ptr()
-            if key not in self.bufs:
-                self.bufs[key] = ops.feature_maps_format([torch.zeros_like(x).cuda() for x in synth.feature_maps_nchw(1, 0, spec["image_wh"])])
-            self.bufs[key][0].copy_(self.staged, non_blocking=True)
-            return self.bufs[key]
-
-    model = Model()
+    model = _StagedModel(build_product_head(spec), spec)
     w, h = spec["image_wh"]
     runner = PipelinedRunner(model, 1, (8, 8), capacity=1536, device=torch.device("cuda"), use_graph=True)
     runner.wh = torch.tensor([float(w), float(h)], device="cuda").view(1, 1, 2).repeat(1, 6, 1)
     runner.wh_host = (w, h)
-    from simpb_amd.plugin import ops
+    return model, runner
+
+
+def test_pipelined_runner_vs_golden():
+    """Backbone(t+1) overlapped with decoder(t): same detections, one step later."""
+    g = load_golden("head_r50.npz")
+    spec = spec_of(g)
+    model, runner = _golden_pipelined_runner(spec)
     outs = []
     for f in range(spec["frames"]):
-        # one persistent staging buffer: extract_feat's copy may be replayed from a captured graph, which
-        # bakes in the source address (a fresh tensor per frame made this test depend on allocator reuse)
-        fresh = ops.feature_maps_format([x.cuda() for x in synth.feature_maps_nchw(1, f, spec["image_wh"])])[0]
-        if getattr(model, "staged", None) is None:
-            model.staged = torch.empty_like(fresh)
-        model.staged.copy_(fresh)
+        model.stage(f)
         torch.cuda.synchronize()
         outs.append(runner.step(runner.img, synth.frame_metas(1, f, spec["image_wh"])))
     outs.append(runner.flush())
@@ -190,15 +199,59 @@ def test_pipelined_equals_plain_runner_with_real_backbone():
                 out.append(r.step(imgs[f], metas[f]))
                 seen.append(snapshot(last["fm"]))
             assert r.stats["replay"] >= 4, r.stats
-        replay = _ReplayModel(make().head)
-        plain = FrameRunner(replay, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=False)
-        for f in range(frames):
-            replay.load(seen[f])
-            a = plain.step(plain.img, metas[f])[0]["img_bbox"]
-            b = out[f][0]["img_bbox"]
-            assert a["boxes_3d"].shape == b["boxes_3d"].shape
-            assert float((a["scores_3d"] - b["scores_3d"]).abs().max()) <= 1e-3, (name, f)
-            assert rows_match_t(a["boxes_3d"], b["boxes_3d"], 1e-3), (name, f)
+        _check_against_replay(make().head, seen, out, metas, wh, name)
+
+
+def _check_against_replay(head, seen, out, metas, wh, name):
+    """Serve the recorded feature maps `seen[f]` to the plain eager runner and compare with `out[f]`."""
+    from simpb_amd.runner import FrameRunner
+    replay = _ReplayModel(head)
+    plain = FrameRunner(replay, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=False)
+    for f in range(len(seen)):
+        replay.load(seen[f])
+        a = plain.step(plain.img, metas[f])[0]["img_bbox"]
+        b = out[f][0]["img_bbox"]
+        assert a["boxes_3d"].shape == b["boxes_3d"].shape
+        assert float((a["scores_3d"] - b["scores_3d"]).abs().max()) <= 1e-3, (name, f)
+        assert rows_match_t(a["boxes_3d"], b["boxes_3d"], 1e-3), (name, f)
+
+
+def test_two_pipelined_runners_side_by_side():
+    """bench.py --streams: independent camera streams, each its own pipelined runner, launched back to back and
+    collected together so that their replayed graphs share the GPU (and their warm-up steps do not: runner.py
+    SERIALIZE_EAGER). One stream runs a frame behind the other; each must return what the plain eager runner
+    returns for the features it recorded."""
+    from simpb_amd import configs, plugin
+    from simpb_amd.runner import PipelinedRunner
+    wh = (352, 128)
+
+    def make():
+        cfg = configs.simpb_plus(anchor=synth.anchors(900))
+        model = plugin.build_detector(cfg["model"]).eval()
+        synth.load_procedural(model)
+        return model.cuda().fuse_conv_bn()
+
+    frames = 12
+    imgs = [synth.images(1, f % 4, wh).cuda() for f in range(frames)]
+    metas = [synth.frame_metas(1, f, wh) for f in range(frames)]
+    runners = [PipelinedRunner(make(), 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=True)
+               for _ in range(2)]
+    lag = (0, 1)
+    outs, seen = [[], []], [[], []]
+    for step in range(frames + 1):
+        live = [i for i in range(2) if 0 <= step - lag[i] < frames]
+        for i in live:
+            runners[i].launch(imgs[step - lag[i]], metas[step - lag[i]])
+        for i in live:
+            f = step - lag[i]
+            outs[i].append(runners[i].collect())
+            if f >= 1:
+                seen[i].append([t.clone() for t in list(runners[i].fm[(f - 1) % 2])[:3]])
+    for i in range(2):
+        seen[i].append([t.clone() for t in list(runners[i].fm[(frames - 1) % 2])[:3]])
+        out = outs[i][1:] + [runners[i].flush()]
+        assert runners[i].stats["replay"] >= 4, runners[i].stats
+        _check_against_replay(make().head, seen[i], out, metas, wh, f"stream{i}")
 
 
 def rows_match_t(a, b, tol):
