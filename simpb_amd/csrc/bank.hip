@@ -57,9 +57,13 @@ __global__ __launch_bounds__(256) void bank_get_kernel(float* __restrict__ out, 
   }
   if (i >= bs * n) return;
   const int b = i / n;
-  const float* a = anchor + (size_t)i * 11;
-  const float* m = T + (size_t)b * 16;
-  const float t = -dt[b];  // anchor_projection(..., time_intervals=[-time_interval]) (:98-101)
+  // The persistent bank buffers are re-read here one frame after other workgroups rewrote them. The loads are
+  // volatile (sc0 sc1: past the vector L1 and any non-coherent L2 line): with plain loads this kernel was the first
+  // one to go wrong when an EAGER decoder ran beside an eager backbone on a second stream (DESIGN.md section 4;
+  // tools/pipe_race.py: 5 bad repetitions in 38 with plain loads, 0 in 22 with these). 6 600 floats: no cost.
+  const volatile float* a = anchor + (size_t)i * 11;
+  const volatile float* m = T + (size_t)b * 16;
+  const float t = -((const volatile float*)dt)[b];  // anchor_projection(..., time_intervals=[-time_interval]) (:98-101)
   const float vx = a[8], vy = a[9], vz = a[10];
   const float cx = a[0] - vx * t, cy = a[1] - vy * t, cz = a[2] - vz * t;
   float* o = out + (size_t)i * 11;
