@@ -1,25 +1,31 @@
 """Build the C-ABI HIP library in-tree: hipcc --offload-arch=gfx950 -> simpb_amd/csrc/libsimpb_hip.so.
-hipcc cross-compiles without a GPU, so this also runs in the build container."""
+hipcc cross-compiles without a GPU, so this also runs in the build container. One hipcc process per source file
+(they are independent translation units), then one link."""
 import glob
+import hashlib
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libsimpb_hip.so")
+STAMP = LIB + ".srchash"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-STAMP = LIB + ".srchash"
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "simpb_hip.h")]
 
 
 def source_hash():
-    import hashlib
     h = hashlib.sha256()
-    for path in sources() + [os.path.join(os.path.dirname(HERE), "include", "simpb_hip.h")]:
+    for path in sources() + headers():
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -33,14 +39,26 @@ def needs_build():
     return open(STAMP).read().strip() != source_hash()
 
 
-def build_extension(force=False, verbose=False):
+def build_extension(force=False, verbose=False, jobs=None):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + sources()
+    os.makedirs(OBJ, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
+        objects = list(pool.map(compile_one, sources()))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objects
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True)
     with open(STAMP, "w") as f:
         f.write(source_hash())
     return LIB

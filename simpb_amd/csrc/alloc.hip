@@ -6,6 +6,7 @@
 // and a <=num_cams-term weighted mean. All byte/index work: HBM-bound, no MFMA.
 #include <hip/hip_runtime.h>
 #include "../../include/simpb_hip.h"
+#include "store_fence.h"
 
 extern "C" int simpb_check_launch(void);
 
@@ -107,7 +108,6 @@ __global__ void alloc_scatter_kernel(float* __restrict__ ref_pts2d, float* __res
   while (cam + 1 < cams && slot >= group_start[cam + 1]) ++cam;
   const int rank = slot - group_start[cam];
   const bool in_set = slot < group_start[cams];  // capacity slots past the last group belong to no camera
-  if (b == 0) query_cam[slot] = in_set ? cam : -1;
   const int bc = b * cams + cam;
   float x = 0.f, y = 0.f, d = 0.f;
   int a = -1, ctr = 0;
@@ -118,8 +118,11 @@ __global__ void alloc_scatter_kernel(float* __restrict__ ref_pts2d, float* __res
     y = sel_xy[2 * o + 1] / img_h;
     d = fabsf(depth[o]);
     ctr = flag[o] == 2;
-    a2q[((size_t)b * A + a) * cams + cam] = slot;
   }
+  simpb::pin(x); simpb::pin(y); simpb::pin(d); simpb::pin(a); simpb::pin(ctr);
+  simpb::loads_retired();  // store_fence.h: every table entry read, then the stores
+  if (b == 0) query_cam[slot] = in_set ? cam : -1;
+  if (a >= 0) a2q[((size_t)b * A + a) * cams + cam] = slot;
   ref_pts2d[2 * (size_t)idx] = x;
   ref_pts2d[2 * (size_t)idx + 1] = y;
   ref_depth2d[idx] = d;
@@ -189,8 +192,13 @@ __global__ void aggregate_kernel(float* __restrict__ out_q, float* __restrict__ 
     }
     const float4 bq = reinterpret_cast<const float4*>(q3d)[row + c];
     const float4 bp = reinterpret_cast<const float4*>(pos3d)[row + c];
-    reinterpret_cast<float4*>(out_q)[row + c] = make_float4(bq.x + sq.x / div, bq.y + sq.y / div, bq.z + sq.z / div, bq.w + sq.w / div);
-    reinterpret_cast<float4*>(out_pos)[row + c] = make_float4(bp.x + sp.x / div, bp.y + sp.y / div, bp.z + sp.z / div, bp.w + sp.w / div);
+    float4 rq = make_float4(bq.x + sq.x / div, bq.y + sq.y / div, bq.z + sq.z / div, bq.w + sq.w / div);
+    float4 rp = make_float4(bp.x + sp.x / div, bp.y + sp.y / div, bp.z + sp.z / div, bp.w + sp.w / div);
+    simpb::pin(rq.x); simpb::pin(rq.y); simpb::pin(rq.z); simpb::pin(rq.w);
+    simpb::pin(rp.x); simpb::pin(rp.y); simpb::pin(rp.z); simpb::pin(rp.w);
+    simpb::loads_retired();  // store_fence.h
+    reinterpret_cast<float4*>(out_q)[row + c] = rq;
+    reinterpret_cast<float4*>(out_pos)[row + c] = rp;
   }
 }
 

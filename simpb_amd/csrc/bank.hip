@@ -6,6 +6,7 @@
 //   cache + get_instance_id + update_instance_id (:152-196) at the end of the frame
 #include <hip/hip_runtime.h>
 #include "../../include/simpb_hip.h"
+#include "store_fence.h"
 
 extern "C" int simpb_check_launch(void);
 
@@ -57,26 +58,30 @@ __global__ __launch_bounds__(256) void bank_get_kernel(float* __restrict__ out, 
   }
   if (i >= bs * n) return;
   const int b = i / n;
-  // The persistent bank buffers are re-read here one frame after other workgroups rewrote them. The loads are
-  // volatile (sc0 sc1: past the vector L1 and any non-coherent L2 line): with plain loads this kernel was the first
-  // one to go wrong when an EAGER decoder ran beside an eager backbone on a second stream (DESIGN.md section 4;
-  // tools/pipe_race.py: 5 bad repetitions in 38 with plain loads, 0 in 22 with these). 6 600 floats: no cost.
-  const volatile float* a = anchor + (size_t)i * 11;
-  const volatile float* m = T + (size_t)b * 16;
-  const float t = -((const volatile float*)dt)[b];  // anchor_projection(..., time_intervals=[-time_interval]) (:98-101)
+  const float* a = anchor + (size_t)i * 11;
+  const float* m = T + (size_t)b * 16;
+  const float t = -dt[b];  // anchor_projection(..., time_intervals=[-time_interval]) (:98-101)
   const float vx = a[8], vy = a[9], vz = a[10];
   const float cx = a[0] - vx * t, cy = a[1] - vy * t, cz = a[2] - vz * t;
-  float* o = out + (size_t)i * 11;
-  o[0] = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
-  o[1] = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
-  o[2] = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
-  o[3] = a[3]; o[4] = a[4]; o[5] = a[5];
   const float s = a[6], c = a[7];  // yaw pair as written in detection3d/blocks.py:271-278
-  o[6] = m[0] * c + m[1] * s;
-  o[7] = m[4] * c + m[5] * s;
-  o[8] = m[0] * vx + m[1] * vy + m[2] * vz;
-  o[9] = m[4] * vx + m[5] * vy + m[6] * vz;
-  o[10] = m[8] * vx + m[9] * vy + m[10] * vz;
+  float r[11];
+  r[0] = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
+  r[1] = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
+  r[2] = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
+  r[3] = a[3]; r[4] = a[4]; r[5] = a[5];
+  r[6] = m[0] * c + m[1] * s;
+  r[7] = m[4] * c + m[5] * s;
+  r[8] = m[0] * vx + m[1] * vy + m[2] * vz;
+  r[9] = m[4] * vx + m[5] * vy + m[6] * vz;
+  r[10] = m[8] * vx + m[9] * vy + m[10] * vz;
+  // all eleven results in registers and every load retired before the first store (store_fence.h): scheduled freely,
+  // the pass-through columns were stored among seven outstanding loads and this kernel faulted beside a busy queue
+#pragma unroll
+  for (int k = 0; k < 11; ++k) simpb::pin(r[k]);
+  simpb::loads_retired();
+  float* o = out + (size_t)i * 11;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) o[k] = r[k];
 }
 
 // ---- update (:137-139): indices of the `fresh` best current instances by max class logit, one workgroup per stream

@@ -5,6 +5,7 @@
 // critical path because the next frame of the stream cannot start before this one has finished.
 #include <hip/hip_runtime.h>
 #include "../../include/simpb_hip.h"
+#include "store_fence.h"
 
 extern "C" int simpb_check_launch(void);
 
@@ -118,16 +119,22 @@ __global__ __launch_bounds__(256) void decode2d_kernel(float* __restrict__ rec2d
     if (row[c] > m) { m = row[c]; arg = c; }
   const float* bx = box2d + (size_t)i * 4;
   const float cx = bx[0], cy = bx[1], w = bx[2], h = bx[3];
-  float* o = rec2d + (size_t)i * 8;
-  o[0] = fminf(fmaxf((cx - 0.5f * w) * crop_w, 0.f), crop_w) * inv_resize;
-  o[1] = (fminf(fmaxf((cy - 0.5f * h) * crop_h, 0.f), crop_h) + crop_y0) * inv_resize;
-  o[2] = fminf(fmaxf((cx + 0.5f * w) * crop_w, 0.f), crop_w) * inv_resize;
-  o[3] = (fminf(fmaxf((cy + 0.5f * h) * crop_h, 0.f), crop_h) + crop_y0) * inv_resize;
-  o[4] = sigmoidf(m);
-  o[5] = (float)arg;
+  float r[8];
+  r[0] = fminf(fmaxf((cx - 0.5f * w) * crop_w, 0.f), crop_w) * inv_resize;
+  r[1] = (fminf(fmaxf((cy - 0.5f * h) * crop_h, 0.f), crop_h) + crop_y0) * inv_resize;
+  r[2] = fminf(fmaxf((cx + 0.5f * w) * crop_w, 0.f), crop_w) * inv_resize;
+  r[3] = (fminf(fmaxf((cy + 0.5f * h) * crop_h, 0.f), crop_h) + crop_y0) * inv_resize;
+  r[4] = sigmoidf(m);
+  r[5] = (float)arg;
   const int a = q2a[i];
-  o[6] = (a >= 0 && a < A) ? (float)rank_of_anchor[(size_t)b * A + a] : -1.f;
-  o[7] = (float)query_cam[slot];
+  r[6] = (a >= 0 && a < A) ? (float)rank_of_anchor[(size_t)b * A + a] : -1.f;
+  r[7] = (float)query_cam[slot];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) simpb::pin(r[k]);
+  simpb::loads_retired();  // store_fence.h
+  float* o = rec2d + (size_t)i * 8;
+  *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
 }
 
 }  // namespace

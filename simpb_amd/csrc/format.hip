@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "../../include/simpb_hip.h"
+#include "store_fence.h"
 
 extern "C" int simpb_check_launch(void);
 
@@ -46,6 +47,9 @@ __global__ void format_tokens_kernel(float* __restrict__ col, LevelArgs lv, int 
       const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) simpb::pin(v[j]);
+    simpb::loads_retired();  // store_fence.h (grid-stride loop: the next row's load must not be in flight at the store)
     float* d = col + ((long long)img * tokens_per_cam + lv.start[lvl] + pix) * C + c;
     *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);

@@ -3,6 +3,7 @@
 // decoder's critical path (each such launch is 2-5 us of dependent latency in the replayed frame).
 #include <hip/hip_runtime.h>
 #include "../../include/simpb_hip.h"
+#include "store_fence.h"
 
 extern "C" int simpb_check_launch(void);
 
@@ -27,18 +28,24 @@ __global__ __launch_bounds__(256) void anchor_projection_kernel(float* __restric
     const float t = dt[b];
     cx -= vx * t; cy -= vy * t; cz -= vz * t;
   }
-  float* o = out + (size_t)i * 11;
   // matmul(T[:3,:3], c) + T[:3,3]: products summed left to right like the batched matmul
-  o[0] = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
-  o[1] = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
-  o[2] = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
-  o[3] = a[3]; o[4] = a[4]; o[5] = a[5];
+  float r[11];
+  r[0] = m[0] * cx + m[1] * cy + m[2] * cz + m[3];
+  r[1] = m[4] * cx + m[5] * cy + m[6] * cz + m[7];
+  r[2] = m[8] * cx + m[9] * cy + m[10] * cz + m[11];
+  r[3] = a[3]; r[4] = a[4]; r[5] = a[5];
   const float s = a[6], c = a[7];
-  o[6] = m[0] * c + m[1] * s;
-  o[7] = m[4] * c + m[5] * s;
-  o[8] = m[0] * vx + m[1] * vy + m[2] * vz;
-  o[9] = m[4] * vx + m[5] * vy + m[6] * vz;
-  o[10] = m[8] * vx + m[9] * vy + m[10] * vz;
+  r[6] = m[0] * c + m[1] * s;
+  r[7] = m[4] * c + m[5] * s;
+  r[8] = m[0] * vx + m[1] * vy + m[2] * vz;
+  r[9] = m[4] * vx + m[5] * vy + m[6] * vz;
+  r[10] = m[8] * vx + m[9] * vy + m[10] * vz;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) simpb::pin(r[k]);
+  simpb::loads_retired();  // store_fence.h: results in registers, loads retired, then the stores
+  float* o = out + (size_t)i * 11;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) o[k] = r[k];
 }
 
 // ---- operands of the grouped multi-scale deformable attention from the fused projection

@@ -135,14 +135,6 @@ class PipelinedRunner(FrameRunner):
     last frame). Two feature buffers alternate; each (backbone, decoder) x (buffer) pair is its own
     hipGraph once warm, so the steady state is two graph launches per step."""
 
-    # Eager (not yet captured) decoder work beside eager or replayed backbone work on the other stream gave wrong
-    # detections in about one run of six on MI355X (tools/pipe_race.py --eager: bit-exact otherwise, garbage
-    # from the first warm frame on when it hits), while two replayed graphs side by side, or everything on one
-    # stream, are bit-exact; so is an eager decoder beside matmuls instead of the vendor convolutions
-    # (--dummy-backbone). Until the cause is pinned down the few eager steps of a stream are serialised and
-    # run alone on the device.
-    SERIALIZE_EAGER = True
-
     def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True):
         super().__init__(model, batch_size, image_hw, capacity, device, use_graph)
         dev = self.device
@@ -253,24 +245,11 @@ class PipelinedRunner(FrameRunner):
                 self.t_buf.copy_(self.pin_t, non_blocking=True)
                 self.dt_buf.copy_(self.pin_dt, non_blocking=True)
 
-    def _replay_only(self, slot, force_eager):
-        """True when this step consists of graph replays alone (backbone of `slot`, decoder of the pending slot)."""
-        if not self.use_graph or force_eager or self.bb_graph[slot] is None:
-            return False
-        if self.pending is None:
-            return True
-        pslot = self.pending[0]
-        return (self.head_graph[pslot] is not None and self.bb_graph[pslot] is not None
-                and self.fm[pslot] is self.bb_out[pslot] and self.prev_metas is not None)
-
     @torch.no_grad()
     def launch(self, img, metas, force_eager=False):
         """Enqueue backbone(t) and decoder(t-1) without waiting for either (several runners -- several
         independent camera streams on one GPU -- can be launched back to back and collected after)."""
         slot = self.count % 2
-        exclusive = self.SERIALIZE_EAGER and not self._replay_only(slot, force_eager)
-        if exclusive:
-            torch.cuda.synchronize()  # other runners of this process (bench.py --streams) included
         cur = torch.cuda.current_stream()
         self.s_bb.wait_stream(cur)
         self.s_head.wait_stream(cur)
@@ -282,15 +261,9 @@ class PipelinedRunner(FrameRunner):
             pslot, pmetas = self.pending
             self._stage_head_inputs(pmetas)
             warm = self.prev_metas is not None
-            if exclusive:
-                # warm-up steps (either side still eager, or about to be captured) run one after the other and alone
-                # on the device: only replayed graphs overlap. See SERIALIZE_EAGER above.
-                self.s_head.wait_stream(self.s_bb)
             rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"], warm, force_eager)
             self._enqueue_readback(rec)
             self._inflight = pmetas
-        if exclusive:
-            torch.cuda.synchronize()
         self._next_pending = (slot, metas)
 
     def collect(self):

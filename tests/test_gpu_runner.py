@@ -218,8 +218,7 @@ def _check_against_replay(head, seen, out, metas, wh, name):
 
 def test_two_pipelined_runners_side_by_side():
     """bench.py --streams: independent camera streams, each its own pipelined runner, launched back to back and
-    collected together so that their replayed graphs share the GPU (and their warm-up steps do not: runner.py
-    SERIALIZE_EAGER). One stream runs a frame behind the other; each must return what the plain eager runner
+    collected together so that their work (eager warm-up steps and replayed graphs alike) shares the GPU. One stream runs a frame behind the other; each must return what the plain eager runner
     returns for the features it recorded."""
     from simpb_amd import configs, plugin
     from simpb_amd.runner import PipelinedRunner

@@ -26,18 +26,24 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--one-stream", action="store_true")
     ap.add_argument("--load", action="store_true")
-    ap.add_argument("--no-serialize", action="store_true", help="PipelinedRunner.SERIALIZE_EAGER = False")
+    ap.add_argument("--no-serialize", action="store_true", help="kept for old command lines: the runner no longer serialises eager steps")
     ap.add_argument("--dummy-backbone", action="store_true",
                     help="backbone stream runs big matmuls + a copy of pre-computed features instead of the convolutions")
     ap.add_argument("--no-miopen", action="store_true", help="torch.backends.cudnn.enabled = False: PyTorch's own convolutions")
     ap.add_argument("--trace", type=int, default=-1, help="frame whose decoder inputs / per-layer outputs are compared")
+    ap.add_argument("--late-clone", action="store_true", help="keep bank_get's output alive and clone it again at the end of the decoder")
+    ap.add_argument("--equal-priority", action="store_true", help="both streams at the default priority")
+    ap.add_argument("--verbose", action="store_true", help="with --trace: print every differing record of the first bad frame")
+    ap.add_argument("--pre-kernel", action="store_true", help="one throw-away launch on the decoder stream in front of bank_get")
+    ap.add_argument("--bank-diag", action="store_true", help="library built with -DSIMPB_BANK_DIAG: print bank_get's self-check log")
+    ap.add_argument("--dump", default="", help="with --trace: save the bank_get operands of the first bad frame here and stop")
     args = ap.parse_args()
     from simpb_amd import configs, plugin, synth
     from simpb_amd.runner import FrameRunner, PipelinedRunner
     wh = (352, 128)
     dev = torch.device("cuda")
-    if args.no_serialize:
-        PipelinedRunner.SERIALIZE_EAGER = False
+    if args.equal_priority:
+        PipelinedRunner.STREAM_PRIORITIES = (0, 0)
     if args.no_miopen:
         torch.backends.cudnn.enabled = False
     if args.load:
@@ -101,9 +107,13 @@ def main():
                 st2 = getattr(bank, "_static", None) or {}
                 if "cached_anchor" in st2:
                     flat("bank_get.in.stored", st2["cached_anchor"], cur["rec"])
+            if args.pre_kernel and getattr(bank, "_static", None):
+                bank._static["prev_id"].add_(0)  # a throw-away launch between the staged copies and bank_get
             res = inner_get(*a, **k)
             if cur["rec"] is not None:
                 flat("bank_get.out", [x for x in res], cur["rec"])
+                if args.late_clone:
+                    cur["warped"] = res[3]
             return res
 
         bank.get = spy_get
@@ -119,6 +129,8 @@ def main():
             flat("in.bank", {k2: v for k2, v in st.items() if torch.is_tensor(v)}, rec)
             outs = inner(fm, metas, *a, **k)
             flat("out", {k2: v for k2, v in outs.items() if k2 != "alloc_list"}, rec)
+            if cur.get("warped") is not None:
+                flat("bank_get.out3_late", cur["warped"], rec)  # same tensor, cloned again at the end of the decoder
             store.append(rec)
             return outs
 
@@ -179,15 +191,50 @@ def main():
             first_bad = next(i for i, x in enumerate(lines[0].split()) if float(x) > 1e-3)
             args.trace = first_bad
             a, b = pipe_trace[args.trace], plain_trace[args.trace]
-            for key in a:
+            k3 = "bank_get.out.3"
+            if k3 in a and k3 in b:
+                pa, pb = a[k3][0].cpu(), b[k3][0].cpu()
+                rows = (pa != pb).any(1).nonzero().flatten().tolist()
+                cols = (pa != pb).any(0).nonzero().flatten().tolist()
+                Tm = a["bank_get.in.T_dt.0"][0].cpu()
+                vals = sorted(set(round(float(x), 5) for x in pa[rows][:, cols].flatten().tolist()))[:6]
+                print(f"    FAULT frame {args.trace}: rows {rows[:3]}..{rows[-3:]} (n={len(rows)}) cols {cols} bad values {vals} "
+                      f"T row0 {[round(float(x), 5) for x in Tm[0]]} row1 {[round(float(x), 5) for x in Tm[1]]} row2 {[round(float(x), 5) for x in Tm[2]]}", flush=True)
+            for key in (a if args.verbose else ()):
                 if key in b and a[key].shape == b[key].shape:
                     d = float((a[key].double() - b[key].double()).abs().max()) if a[key].numel() else 0.0
                     if d != 0.0 or key.startswith("in.") or key.startswith("bank_get"):
                         print(f"    trace frame {args.trace} {key:40s} max|pipe - plain| = {d:.3e}  max|pipe| = {float(a[key].double().abs().max()) if a[key].numel() else 0:.3e}")
                 else:
                     print(f"    trace frame {args.trace} {key:40s} only in pipe or shape differs")
+            if args.dump:
+                keep = lambda tr, f: {k: v.cpu() for k, v in tr[f].items() if k.startswith(("bank_get", "in.bank"))}  # noqa: E731
+                torch.save({"frame": first_bad, "pipe": keep(pipe_trace, first_bad), "plain": keep(plain_trace, first_bad),
+                            "pipe_prev": keep(pipe_trace, first_bad - 1), "plain_prev": keep(plain_trace, first_bad - 1)},
+                           args.dump)
+                print(f"rep {rep}: dumped frame {first_bad} to {args.dump}", flush=True)
+                bad_stop = True
+        if args.bank_diag:
+            import ctypes
+            import numpy as np
+            from simpb_amd import _lib
+            fn = _lib.lib().simpb_debug_bank_faults
+            fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int
+            cnt = ctypes.c_uint(0)
+            buf = np.zeros((64, 24), np.float32)
+            torch.cuda.synchronize()
+            fn(ctypes.byref(cnt), buf.ctypes.data)
+            seen_cnt = getattr(args, "_diag_seen", 0)
+            if cnt.value > seen_cnt:
+                names = "i r0 q0 w0 r6 q6 w6 m0 m1 m2 m3 n0 n1 n2 n3 cx cy cz x2 y2 s c".split()
+                for e in buf[seen_cnt:min(cnt.value, 64)]:
+                    hw = e[22:24].view(np.uint32)
+                    print("    DIAG " + " ".join(f"{k}={v:.5g}" for k, v in zip(names, e[:22])) + f" hw_id={hw[0]:#x} xcc={hw[1]:#x}", flush=True)
+                args._diag_seen = cnt.value
         print(f"rep {rep}: pipe-vs-plainA {lines[0]}\n        pipe-vs-plainB {lines[1]}", flush=True)
-    print(f"BAD {bad}/{args.reps}", flush=True)
+        if args.dump and locals().get("bad_stop"):
+            break
+    print(f"BAD {bad}/{rep + 1}", flush=True)
 
 
 if __name__ == "__main__":
