@@ -48,6 +48,9 @@ def parse():
                     help="independent camera streams per GPU, each a bs-sized runner of its own replayed concurrently "
                          "(BASELINE config #3 shape: 8 streams per GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
+    ap.add_argument("--h2d", action="store_true",
+                    help="frames start in pinned host memory and cross PCIe inside the timed step (async copy on the backbone "
+                         "stream, beside the previous frame's decoder); default: inputs resident in HBM, as `value` requires")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
@@ -207,11 +210,16 @@ def main():
     # the box's CPU share (a pool sized to the machine's core count stalls frames for tens of ms)
     torch.set_num_threads(max(1, min(4, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
 
-    from simpb_amd.dist import gather_detections, pack_detections
+    from simpb_amd.dist import DetectionGather
     from simpb_amd.runner import FrameRunner, PipelinedRunner
     torch.backends.cudnn.benchmark = not args.no_conv_search
     total = args.prime + args.warmup + args.steps + args.meter_frames
     imgs = make_frames(args, device, total)
+    if args.h2d:  # the reference's protocol times model(**data) with the scatter to the device inside (tools/benchmark.py:90-100)
+        imgs = [x.cpu().pin_memory() for x in imgs]
+
+    def frame_of(f):
+        return imgs[f % len(imgs)]
     metas = [frame_metas(args, f) for f in range(total)]  # what a dataloader would hand over
     pipelined = not args.no_pipeline and not args.eager
     if args.streams > 1 and not pipelined:
@@ -223,16 +231,15 @@ def main():
             model, args.bs, (args.image_wh[1], args.image_wh[0]), capacity=args.capacity, device=device,
             use_graph=not args.eager))
     runner = runners[0]
-    gathered = None
-    side = torch.cuda.Stream(device=device)
+    # N > 1: the fixed-shape device record of every stream to every rank, one all-gather per frame on a side stream
+    gather = DetectionGather(args.streams * args.bs, runner.head.decoder.num_output, device) if dist is not None else None
 
     def step(f, force_eager=False):
-        nonlocal gathered
         if len(runners) == 1:
-            results = runner.step(imgs[f % len(imgs)], metas[f], force_eager=force_eager)
-        else:  # launch every stream's frame, then collect: the streams' graphs run side by side
+            results = runner.step(frame_of(f), metas[f], force_eager=force_eager)
+        else:  # launch every stream's frame, then collect: the streams' work runs side by side
             for i, r in enumerate(runners):
-                r.launch(imgs[(f + i) % len(imgs)], metas[f], force_eager=force_eager)
+                r.launch(frame_of(f + i), metas[f], force_eager=force_eager)
             results = None
             for r in runners:
                 out = r.collect()
@@ -240,14 +247,10 @@ def main():
                     results = (results or []) + out
         if results is None:  # pipelined runner, very first call: nothing decoded yet
             return None
-        if dist is not None:  # detections of every stream to every rank, off the compute stream
-            if args.backend == "nccl":
-                rec = pack_detections(results, device)
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    gathered = gather_detections(rec, gathered)
-            else:
-                gathered = gather_detections(pack_detections(results), gathered)
+        if gather is not None:
+            gather.submit([r.last_rec3d for r in runners], [r.s_head for r in runners if hasattr(r, "s_head")])
+            for r in runners:
+                r.rec_consumed = gather.done
         return results
 
     first = args.prime + args.warmup
@@ -274,7 +277,7 @@ def main():
         with KernelMeter(args.meter_frames) as kt:
             kt.start()
             for f in range(first + args.steps, total):
-                runner.step(imgs[f % len(imgs)], metas[f], force_eager=True)  # rank-local: no collective here
+                runner.step(frame_of(f), metas[f], force_eager=True)  # rank-local: no collective here
             torch.cuda.synchronize()
             ksum = kt.summary()
 

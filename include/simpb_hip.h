@@ -18,6 +18,8 @@ extern "C" {
 #define SIMPB_EINVAL 1   /* null pointer, non-positive size, or a layout the kernels cannot take */
 #define SIMPB_ELAUNCH 2  /* hipGetLastError() after the launch was not hipSuccess */
 
+#define SIMPB_RECORD3D_WIDTH 15 /* columns of the 3D detection record (simpb_decode3d_record) */
+
 /* Library/ABI version (bumped when a signature changes). */
 int simpb_abi_version(void);
 
@@ -262,7 +264,9 @@ int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream);
  *   frame's, used when has_previous; out: this frame's), cached_feature [bs, T, C] / cached_anchor [bs, T, 11] out,
  *   instance_id i64 [bs, A] in/out (may be NULL), prev_id i64 [1] in/out, ids_out i64 [bs, A] = the ids
  *   get_instance_id returns; fresh ids are numbered over the flattened batch (:179-181); threshold applies to
- *   sigmoid(max class logit) when has_threshold. index_scratch i32 [bs, T]. */
+ *   sigmoid(max class logit) when has_threshold. index_scratch i32 [bs, T]. hold i32 [num_hold] (may be NULL with
+ *   num_hold = 0): overflow flags of this frame's 2D query sets (simpb_alloc_group_start); when any is non-zero the
+ *   call writes NOTHING, so that the caller can re-run the frame with a larger capacity on the state the frame found. */
 int simpb_bank_get(float* anchor_out, unsigned char* mask_out, float* time_interval_out, const float* cached_anchor,
                    const float* T_temp2cur, const float* time_interval, int batch_size, int num_temp,
                    float max_time_interval, float default_time_interval, void* stream);
@@ -273,13 +277,16 @@ int simpb_bank_update(float* feature_out, float* anchor_out, long long* instance
 int simpb_bank_cache(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
                      long long* prev_id, long long* ids_out, int* index_scratch, const float* feature, const float* anchor,
                      const float* cls, int batch_size, int num_anchors, int num_classes, int num_temp, int embed_dims,
-                     int has_previous, float confidence_decay, int has_threshold, float threshold, void* stream);
+                     int has_previous, float confidence_decay, int has_threshold, float threshold, const int* hold,
+                     int num_hold, void* stream);
 
 /* Fixed-shape detection records of SparseBox3DDecoder.decode_with2d (models/detection3d/decoder.py:124-252).
  * 3D (:133-167 with squeezed classes + decode_box :23-34), one workgroup per sample:
  *   score = max_c sigmoid(cls); the num_output best anchors; re-scored by sigmoid(quality[..., 0]) (quality
- *   may be NULL) and sorted again; rec3d f32 [bs, num_output, 14] = x y z exp(w) exp(l) exp(h) atan2(sin, cos)
- *   vx vy vz | score | label | score before the re-score | instance id (or -1); rank_of_anchor i32 [bs, A] =
+ *   may be NULL) and sorted again; rec3d f32 [bs, num_output, SIMPB_RECORD3D_WIDTH = 15] = x y z exp(w) exp(l) exp(h)
+ *   atan2(sin, cos) vx vy vz | score | label | score before the re-score | the int64 instance id (or -1) as two
+ *   32-bit lanes, low dword first, bit-cast into columns 13 and 14 (read them back through an int64 view: the
+ *   reference keeps ids int64 end to end, decoder.py:247-251, and a float is exact only up to 2^24); rank_of_anchor i32 [bs, A] =
  *   rank of the anchor in that order, or -1. cls f32 [bs, A, C]; quality f32 [bs, A, 2]; box f32 [bs, A, 11];
  *   instance_id i64 [bs, A] or NULL. A <= 1024, num_output <= 512.
  * 2D (:168-175 + decode_box2d :36-51), one thread per slot: rec2d f32 [bs, N2, 8] = xyxy box in original image

@@ -199,6 +199,7 @@ __global__ void aggregate_kernel(float* __restrict__ out_q, float* __restrict__ 
     simpb::loads_retired();  // store_fence.h
     reinterpret_cast<float4*>(out_q)[row + c] = rq;
     reinterpret_cast<float4*>(out_pos)[row + c] = rp;
+    simpb::loads_retired();  // (also a store fence: the next channel slice loads with nothing in flight)
   }
 }
 

@@ -52,15 +52,25 @@ __global__ __launch_bounds__(256) void bank_get_kernel(float* __restrict__ out, 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < bs) {
     const float t = dt[i];
+    simpb::loads_retired();
     const bool ok = fabsf(t) <= max_dt;  // :87
     mask[i] = ok ? 1 : 0;
     dt_out[i] = (t != 0.f && ok) ? t : default_dt;  // :108-113
+    simpb::loads_retired();  // (a store fence as well: nothing in flight when the rows below are loaded)
   }
   if (i >= bs * n) return;
   const int b = i / n;
-  const float* a = anchor + (size_t)i * 11;
-  const float* m = T + (size_t)b * 16;
+  float a[11], m[12];
+  {
+    const float* ap = anchor + (size_t)i * 11;
+    const float* mp = T + (size_t)b * 16;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) a[k] = ap[k];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = mp[k];
+  }
   const float t = -dt[b];  // anchor_projection(..., time_intervals=[-time_interval]) (:98-101)
+  simpb::loads_retired();  // every consumer behind a full vmcnt(0): no counted waits in this kernel
   const float vx = a[8], vy = a[9], vz = a[10];
   const float cx = a[0] - vx * t, cy = a[1] - vy * t, cz = a[2] - vz * t;
   const float s = a[6], c = a[7];  // yaw pair as written in detection3d/blocks.py:271-278
@@ -124,18 +134,29 @@ __global__ __launch_bounds__(64) void bank_merge_kernel(float* __restrict__ out_
   if (!use && instance_id && lane == 0) instance_id[(size_t)b * A + r] = -1;
 }
 
+// A frame whose 2D query set overflowed its static capacity is re-run by the caller with a larger one
+// (simpb_amd/runner.py); `hold` are that frame's overflow flags (simpb_alloc_group_start): when any is set the
+// frame-end commit below leaves the persistent state exactly as the frame found it.
+__device__ __forceinline__ bool held(const int* hold, int num_hold) {
+  bool h = false;
+  for (int k = 0; k < num_hold; ++k) h |= hold[k] != 0;
+  return h;
+}
+
 // ---- cache (:152-167) + get_instance_id (:169-184) + update_instance_id (:186-196): ONE workgroup walks the
 // streams in order (fresh track ids are numbered over the flattened batch, :179-181).
 __global__ __launch_bounds__(512) void bank_cache_kernel(float* __restrict__ conf, int* __restrict__ index,
                                                          long long* __restrict__ ids_out, long long* __restrict__ instance_id,
                                                          long long* __restrict__ prev_id, const float* __restrict__ cls,
                                                          int bs, int A, int C, int T, int has_prev, float decay,
-                                                         int has_threshold, float threshold) {
+                                                         int has_threshold, float threshold, const int* __restrict__ hold,
+                                                         int num_hold) {
   __shared__ unsigned long long key[kCap];
   __shared__ long long ids[kCap];
   __shared__ int scan[kCap];
   __shared__ float fresh_score[kCap];
   const int tid = threadIdx.x;
+  if (held(hold, num_hold)) return;  // wave-uniform: the frame is re-run by the caller, the state stays as it was
   long long next_id = *prev_id;
   for (int b = 0; b < bs; ++b) {
     // scores: sigmoid of the best class; tracked instances keep max(decayed previous, new) (:157-162)
@@ -196,8 +217,10 @@ __global__ __launch_bounds__(512) void bank_cache_kernel(float* __restrict__ con
 // ---- cache: kept rows of the feature / anchor tables into the persistent state, one wave per row
 __global__ __launch_bounds__(64) void bank_gather_kernel(float* __restrict__ out_f, float* __restrict__ out_a,
                                                          const float* __restrict__ src_f, const float* __restrict__ src_a,
-                                                         const int* __restrict__ index, int A, int T, int C) {
+                                                         const int* __restrict__ index, int A, int T, int C,
+                                                         const int* __restrict__ hold, int num_hold) {
   const int r = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  if (held(hold, num_hold)) return;
   const int src = index[(size_t)b * T + r];
   const float* sf = src_f + ((size_t)b * A + src) * C;
   float* of = out_f + ((size_t)b * T + r) * C;
@@ -242,16 +265,18 @@ extern "C" int simpb_bank_cache(float* confidence, float* cached_feature, float*
                                 long long* prev_id, long long* ids_out, int* index_scratch, const float* feature,
                                 const float* anchor, const float* cls, int batch_size, int num_anchors, int num_classes,
                                 int num_temp, int embed_dims, int has_previous, float confidence_decay, int has_threshold,
-                                float threshold, void* stream) {
+                                float threshold, const int* hold, int num_hold, void* stream) {
   if (!confidence || !cached_feature || !cached_anchor || !prev_id || !ids_out || !index_scratch || !feature || !anchor ||
       !cls || batch_size <= 0 || num_anchors <= 0 || num_anchors > kCap || num_classes <= 0 || num_temp <= 0 ||
-      num_temp > num_anchors || embed_dims <= 0 || (embed_dims & 3) || batch_size > 65535)
+      num_temp > num_anchors || embed_dims <= 0 || (embed_dims & 3) || batch_size > 65535 || num_hold < 0 ||
+      (num_hold > 0 && !hold))
     return SIMPB_EINVAL;
   (void)hipGetLastError();
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bank_cache_kernel, dim3(1), dim3(512), 0, s, confidence, index_scratch, ids_out, instance_id, prev_id, cls,
-                     batch_size, num_anchors, num_classes, num_temp, has_previous, confidence_decay, has_threshold, threshold);
+                     batch_size, num_anchors, num_classes, num_temp, has_previous, confidence_decay, has_threshold, threshold, hold,
+                     num_hold);
   hipLaunchKernelGGL(bank_gather_kernel, dim3(num_temp, batch_size), dim3(64), 0, s, cached_feature, cached_anchor, feature,
-                     anchor, index_scratch, num_anchors, num_temp, embed_dims);
+                     anchor, index_scratch, num_anchors, num_temp, embed_dims, hold, num_hold);
   return simpb_check_launch();
 }

@@ -90,15 +90,25 @@ __global__ __launch_bounds__(512) void decode3d_kernel(float* __restrict__ rec3d
     unsigned uo = (unsigned)(key[r] >> 32);
     uo = (uo & 0x80000000u) ? (uo & 0x7FFFFFFFu) : ~uo;
     const float* bx = box + ((size_t)b * A + a) * 11;
-    float* o = rec3d + ((size_t)b * K + r) * 14;
-    o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2];
-    o[3] = expf(bx[3]); o[4] = expf(bx[4]); o[5] = expf(bx[5]);
-    o[6] = atan2f(bx[6], bx[7]);
-    o[7] = bx[8]; o[8] = bx[9]; o[9] = bx[10];
-    o[10] = score;
-    o[11] = (float)label[a];
-    o[12] = __uint_as_float(uo);
-    o[13] = instance_id ? (float)instance_id[(size_t)b * A + a] : -1.f;
+    float v[SIMPB_RECORD3D_WIDTH];
+    v[0] = bx[0]; v[1] = bx[1]; v[2] = bx[2];
+    v[3] = expf(bx[3]); v[4] = expf(bx[4]); v[5] = expf(bx[5]);
+    v[6] = atan2f(bx[6], bx[7]);
+    v[7] = bx[8]; v[8] = bx[9]; v[9] = bx[10];
+    v[10] = score;
+    v[11] = (float)label[a];
+    v[12] = __uint_as_float(uo);
+    // the int64 track id travels bit-exactly as two 32-bit lanes (a float holds integers only up to 2^24, which a
+    // stream passes after ~56 k frames at 300 fresh ids per frame); read back with an int64 view of columns 13:15
+    const long long id = instance_id ? instance_id[(size_t)b * A + a] : -1ll;
+    v[13] = __uint_as_float((unsigned)((unsigned long long)id & 0xFFFFFFFFull));
+    v[14] = __uint_as_float((unsigned)((unsigned long long)id >> 32));
+#pragma unroll
+    for (int k = 0; k < SIMPB_RECORD3D_WIDTH; ++k) simpb::pin(v[k]);
+    simpb::loads_retired();  // store_fence.h
+    float* o = rec3d + ((size_t)b * K + r) * SIMPB_RECORD3D_WIDTH;
+#pragma unroll
+    for (int k = 0; k < SIMPB_RECORD3D_WIDTH; ++k) o[k] = v[k];
     rank_of_anchor[(size_t)b * A + a] = r;
   }
 }

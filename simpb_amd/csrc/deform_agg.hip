@@ -13,6 +13,7 @@
 // 16-byte load per lane = one coalesced 1-KiB row per wave-instruction at C = 256. Sums stay in
 // registers; the 4 waves meet once in LDS and the row is written once -> deterministic.
 #include <hip/hip_runtime.h>
+#include "store_fence.h"
 #include "../../include/simpb_hip.h"
 
 extern "C" int simpb_check_launch(void);
@@ -113,6 +114,12 @@ __global__ __launch_bounds__(kThreads) void daf_fwd_rows(
                    x1, y1, ld_off);
         wg1 = wrow[((size_t)i1 * L + lvl) * G];
       }
+      // Both samples' rows (8 x 1 KiB per wave) and weights are requested; wait for ALL of them, then do the arithmetic.
+      // Round 2: with counted waits (accumulate sample 0 while sample 1's rows are still arriving) this kernel, like
+      // bank_get and dfa_points, occasionally produced a wrong partial sum in lanes 48-63 of one wave when another
+      // hardware queue kept the chip busy (store_fence.h); a full wait costs nothing measurable here, the other
+      // waves of the CU cover the latency.
+      simpb::loads_retired();
       accumulate(acc, t0, wg0);
       if (i1 >= 0) accumulate(acc, t1, wg1);
     }
@@ -163,7 +170,10 @@ __global__ void daf_fwd_generic(float* __restrict__ out, const float* __restrict
           acc += weights[(li * L + lvl) * G + g] * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
         }
       }
+    simpb::pin(acc);
+    simpb::loads_retired();  // store_fence.h (channel loop: the next channel's loads start with nothing in flight)
     out[row * C + c] = acc;
+    simpb::loads_retired();
   }
 }
 
@@ -198,7 +208,9 @@ extern "C" int simpb_deformable_aggregation_forward(
   return simpb_check_launch();
 }
 
-extern "C" int simpb_abi_version(void) { return 2; }  // 2: simpb_mlp_chain gained the post stage (8 chains per launch)
+// 2: simpb_mlp_chain gained the post stage (8 chains per launch); 3: simpb_bank_cache takes the hold flags, the 3D
+// record carries the int64 track id in two lanes (15 columns)
+extern "C" int simpb_abi_version(void) { return 3; }
 
 // ---- optional per-launch HIP-event timing (bench.py's roofline leg). Events are recorded on the
 // launch stream immediately around the kernel launch, inside the same C call, so the interval

@@ -11,6 +11,7 @@
 //    weights_fc(feature + cam_embed) = weights_fc(feature) + cam_embed @ W^T.
 #include <hip/hip_runtime.h>
 #include "../../include/simpb_hip.h"
+#include "store_fence.h"
 
 extern "C" int simpb_check_launch(void);
 
@@ -26,34 +27,55 @@ __global__ void dfa_points_kernel(float* __restrict__ loc, float* __restrict__ k
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= bs * A * P) return;
   const int p = idx % P, a = (idx / P) % A, b = idx / (P * A);
+  // store_fence.h discipline: every consumer of loaded data sits behind a full vmcnt(0), and no store is in flight
+  // while a counted wait releases consumers (this kernel, scheduled freely, stored camera c's pair while camera c+1's
+  // matrix rows were on their way behind counted waits, and faulted in lanes 48-63 beside a busy second queue)
   const float* an = anchor + ((size_t)b * A + a) * 11;
-  const float sw = expf(an[3]), sl = expf(an[4]), sh = expf(an[5]);
-  float kx, ky, kz;
+  float av[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) av[k] = an[k];
+  float f0 = 0.f, f1 = 0.f, f2 = 0.f;
   if (p < num_fix) {
-    kx = fix_scale[p * 3 + 0] * sw; ky = fix_scale[p * 3 + 1] * sl; kz = fix_scale[p * 3 + 2] * sh;
+    f0 = fix_scale[p * 3 + 0]; f1 = fix_scale[p * 3 + 1]; f2 = fix_scale[p * 3 + 2];
   } else {
     const float* l = learn + (((size_t)b * A + a) * num_learn + (p - num_fix)) * 3;
-    kx = (1.f / (1.f + expf(-l[0])) - 0.5f) * sw;
-    ky = (1.f / (1.f + expf(-l[1])) - 0.5f) * sl;
-    kz = (1.f / (1.f + expf(-l[2])) - 0.5f) * sh;
+    f0 = l[0]; f1 = l[1]; f2 = l[2];
   }
-  const float sn = an[6], cs = an[7];
-  const float px = cs * kx - sn * ky + an[0];
-  const float py = sn * kx + cs * ky + an[1];
-  const float pz = kz + an[2];
+  simpb::loads_retired();
+  const float sw = expf(av[3]), sl = expf(av[4]), sh = expf(av[5]);
+  float kx, ky, kz;
+  if (p < num_fix) {
+    kx = f0 * sw; ky = f1 * sl; kz = f2 * sh;
+  } else {
+    kx = (1.f / (1.f + expf(-f0)) - 0.5f) * sw;
+    ky = (1.f / (1.f + expf(-f1)) - 0.5f) * sl;
+    kz = (1.f / (1.f + expf(-f2)) - 0.5f) * sh;
+  }
+  const float sn = av[6], cs = av[7];
+  float px = cs * kx - sn * ky + av[0];
+  float py = sn * kx + cs * ky + av[1];
+  float pz = kz + av[2];
   if (key_points) {
+    simpb::pin(px); simpb::pin(py); simpb::pin(pz);
     float* kp = key_points + (size_t)idx * 3;
     kp[0] = px; kp[1] = py; kp[2] = pz;
   }
   for (int c = 0; c < cams; ++c) {
     const float* M = proj + ((size_t)b * cams + c) * 16;
-    const float u = M[0] * px + M[1] * py + M[2] * pz + M[3];
-    const float v = M[4] * px + M[5] * py + M[6] * pz + M[7];
-    const float d = fmaxf(M[8] * px + M[9] * py + M[10] * pz + M[11], 1e-5f);
     const float* wh = image_wh + ((size_t)b * cams + c) * 2;
+    float m[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = M[k];
+    const float w0 = wh[0], w1 = wh[1];
+    simpb::loads_retired();  // also retires the previous camera's stores
+    const float u = m[0] * px + m[1] * py + m[2] * pz + m[3];
+    const float v = m[4] * px + m[5] * py + m[6] * pz + m[7];
+    const float d = fmaxf(m[8] * px + m[9] * py + m[10] * pz + m[11], 1e-5f);
+    float r0 = u / d / w0, r1 = v / d / w1;
+    simpb::pin(r0); simpb::pin(r1);
     float* o = loc + ((size_t)idx * cams + c) * 2;
-    o[0] = u / d / wh[0];
-    o[1] = v / d / wh[1];
+    o[0] = r0;
+    o[1] = r1;
   }
 }
 

@@ -20,14 +20,20 @@ __global__ __launch_bounds__(256) void anchor_projection_kernel(float* __restric
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= bs * n) return;
   const int b = i / n;
-  const float* a = anchor + (size_t)i * 11;
-  const float* m = T + (size_t)b * 16;
-  float cx = a[0], cy = a[1], cz = a[2];
-  const float vx = a[8], vy = a[9], vz = a[10];
-  if (dt) {
-    const float t = dt[b];
-    cx -= vx * t; cy -= vy * t; cz -= vz * t;
+  float a[11], m[12];
+  {
+    const float* ap = anchor + (size_t)i * 11;
+    const float* mp = T + (size_t)b * 16;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) a[k] = ap[k];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = mp[k];
   }
+  const float t = dt ? dt[b] : 0.f;
+  simpb::loads_retired();  // store_fence.h: every consumer behind a full vmcnt(0)
+  const float vx = a[8], vy = a[9], vz = a[10];
+  float cx = a[0], cy = a[1], cz = a[2];
+  if (dt) { cx -= vx * t; cy -= vy * t; cz -= vz * t; }
   // matmul(T[:3,:3], c) + T[:3,3]: products summed left to right like the batched matmul
   float r[11];
   r[0] = m[0] * cx + m[1] * cy + m[2] * cz + m[3];

@@ -41,18 +41,19 @@ class DynamicQueryAllocation(nn.Module):
         self.limit_corners_num = limit_corners_num
         self.last = None
 
-    def forward(self, anchor3d, metas, dense=True, capacity=None):
+    def forward(self, anchor3d, metas, dense=True, capacity=None, overflow_out=None):
         """Returns the reference's 8-tuple (allocation.py:144). With dense=True the two one-hot
         matrices are materialised from the index form; with dense=False their places hold None
         and callers use `self.last` (an Allocation2D) instead."""
-        alloc, ref_pts2d, ref_depth2d, trans_mask, trans_shape = self.allocate(anchor3d, metas, capacity)
+        alloc, ref_pts2d, ref_depth2d, trans_mask, trans_shape = self.allocate(anchor3d, metas, capacity, overflow_out)
         trans, center = alloc.dense() if dense else (None, None)
         return ref_pts2d, ref_depth2d, trans_mask, trans_shape, trans, center, alloc.query_groups, None
 
-    def allocate(self, anchor3d, metas, capacity=None):
+    def allocate(self, anchor3d, metas, capacity=None, overflow_out=None):
         """capacity=None: size the 2D set exactly (one count readback, like allocation.py:94).
         capacity=N: static shapes, no host round trip; the group table stays on the device, slots
-        past the last group carry query_cam = -1, and `overflow` flags a set that did not fit."""
+        past the last group carry query_cam = -1, and `overflow` (i32 [1]; `overflow_out` when the caller keeps the
+        flags of a frame's layers in one tensor) flags a set that did not fit."""
         if self.training:
             raise NotImplementedError("training-time corner sampling (allocation.py:85-87) is not on this path")
         _require_gpu(anchor3d)
@@ -90,7 +91,9 @@ class DynamicQueryAllocation(nn.Module):
         else:
             cum, n2 = None, int(capacity)
             group_start = torch.empty(cams + 1, dtype=torch.int32, device=dev)
-            overflow = torch.empty(1, dtype=torch.int32, device=dev)
+            overflow = overflow_out if overflow_out is not None else torch.empty(1, dtype=torch.int32, device=dev)
+            if overflow.dtype != torch.int32 or overflow.numel() != 1 or overflow.device != dev:
+                raise ValueError("overflow_out must be one i32 element on the anchors' device")
             _lib.check(lib.simpb_alloc_group_start(_ptr(group_start), _ptr(overflow), _ptr(count), bs, cams, n2, st),
                        "simpb_alloc_group_start")
         ref_pts2d = torch.empty(bs, n2, 2, device=dev)

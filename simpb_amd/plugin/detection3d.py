@@ -354,8 +354,9 @@ class SparseBox3DDecoder(object):
     # from two small fixed-shape records.
     def decode_static_device(self, cls_scores, box_preds, instance_id, qulity, cls_scores2d, box_preds2d, alloc,
                              aug_config, output_idx=-1, output_idx2d=-1):
-        """Returns (rec3d f32 [bs, num_output, 14], rec2d f32 [bs, N2cap, 8]):
-        rec3d = 10 decoded box + score + label + pre-centerness score + instance id (decoder.py:133-167, 23-34);
+        """Returns (rec3d f32 [bs, num_output, 15], rec2d f32 [bs, N2cap, 8]):
+        rec3d = 10 decoded box + score + label + pre-centerness score + the int64 instance id bit-cast into two
+        lanes (decoder.py:133-167, 23-34; include/simpb_hip.h);
         rec2d = 4 decoded box + score + label + rank of the slot's anchor in the sorted top-k (or -1)
         + camera of the slot (or -1)."""
         cls3, box3 = cls_scores[output_idx], box_preds[output_idx]
@@ -371,8 +372,9 @@ class SparseBox3DDecoder(object):
         box3d = self.decode_box(box.reshape(bs * k, d)).reshape(bs, k, -1)
         labels = torch.gather(cls_ids, 1, indices)
         ids = torch.gather(instance_id, 1, indices)
+        from ..dist import ids_to_lanes
         rec3d = torch.cat([box3d, scores[..., None], labels[..., None].to(box3d.dtype), origin[..., None],
-                           ids[..., None].to(box3d.dtype)], dim=-1)
+                           ids_to_lanes(ids)], dim=-1)
         q2a = alloc.q2a.long()
         num_anchor = box_preds[output_idx].shape[1]
         rank_of_anchor = torch.full((bs, num_anchor + 1), -1, dtype=torch.long, device=q2a.device)
@@ -396,7 +398,7 @@ class SparseBox3DDecoder(object):
         cls3, box3 = cls3.contiguous().float(), box3.contiguous().float()
         quality = quality.contiguous().float() if quality is not None else None
         ids = instance_id.contiguous().long() if instance_id is not None else None
-        rec3d = torch.empty(bs, k, 14, device=dev)
+        rec3d = torch.empty(bs, k, 15, device=dev)
         rank = torch.empty(bs, num_anchor, dtype=torch.int32, device=dev)
         _lib.check(lib.simpb_decode3d_record(_ptr(rec3d), _ptr(rank), _ptr(cls3), _ptr(quality) if quality is not None else None,
                                              _ptr(box3), _ptr(ids) if ids is not None else None, bs, num_anchor, num_cls, k,
@@ -446,7 +448,7 @@ class SparseBox3DDecoder(object):
             t = torch.from_numpy
             output.append({
                 "boxes_3d": t(r3[:, :10].copy()), "scores_3d": t(r3[:, 10].copy()), "labels_3d": t(r3[:, 11].astype(np.int64)),
-                "cls_scores": t(r3[:, 12].copy()), "instance_ids": t(r3[:, 13].astype(np.int64)),
+                "cls_scores": t(r3[:, 12].copy()), "instance_ids": t(np.ascontiguousarray(r3[:, 13:15]).view(np.int64)[:, 0].copy()),
                 "boxes_2d": t(r2[idx2d, :4]), "scores_2d": t(r2[idx2d, 4]), "labels_2d": t(r2[idx2d, 5].astype(np.int64)),
                 "camidx_2d": t(np.concatenate(camidx_2d)), "trans_matrix": t(trans_t), "query_groups": query_groups,
             })

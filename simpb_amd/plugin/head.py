@@ -250,6 +250,12 @@ class SimPBHead(BaseModule):
         alloc = None
         self._m_live = None
         last = len(self.operation_order) - 1
+        # static mode: the overflow flags of the frame's allocation layers in one tensor; the frame-end commit of the
+        # bank holds back when any is set, so that the caller can re-run the frame (runner.py) on untouched state
+        overflow = None
+        if cap is not None:
+            overflow = torch.zeros(sum(op == "allocation" for op in self.operation_order), dtype=torch.int32,
+                                   device=anchor.device)
 
         for i, op in enumerate(self.operation_order):
             layer = self.layers[i]
@@ -264,8 +270,10 @@ class SimPBHead(BaseModule):
                 instance_feature = layer(instance_feature, m_live=self._m_live)
             elif op == "allocation":
                 assert self.instance_status == "3d"
+                k = len(ref_pts2d_list)
                 anchor2d, ref_depth2d, ref_trans_mask, ref_trans_shape, _, _, ref_query_groups, _ = layer(
-                    anchor, metas, dense=False, capacity=cap)
+                    anchor, metas, dense=False, capacity=cap,
+                    overflow_out=overflow[k:k + 1] if overflow is not None else None)
                 alloc = layer.last
                 if cap is not None and batch_size == 1 and alloc.group_start is not None:
                     self._m_live = alloc.group_start[self.num_cams: self.num_cams + 1]
@@ -336,9 +344,10 @@ class SimPBHead(BaseModule):
             "prediction_alpha2d": prediction_alpha2d, "prediction_depth2d": prediction_depth2d,
             "ref_pts2d_list": ref_pts2d_list, "ref_trans_shape_list": ref_trans_shape_list,
             "ref_trans_matrix_list": ref_trans_matrix_list, "ref_query_groups_list": ref_query_groups_list,
-            "alloc_list": alloc_list,
+            "alloc_list": alloc_list, "overflow": overflow,
         }
-        ids = self.instance_bank.cache_and_assign_ids(instance_feature, anchor, cls, metas, self.decoder.score_threshold)
+        ids = self.instance_bank.cache_and_assign_ids(instance_feature, anchor, cls, metas, self.decoder.score_threshold,
+                                                      hold=overflow)
         if ids is None:
             self.instance_bank.cache(instance_feature, anchor, cls, metas, feature_maps)
             ids = self.instance_bank.get_instance_id(cls, anchor, self.decoder.score_threshold)

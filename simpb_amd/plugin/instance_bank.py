@@ -231,10 +231,11 @@ class InstanceBank(nn.Module):
                 and self.num_anchor <= 1024 and 0 < self.num_temp_instances < self.num_anchor
                 and self.embed_dims % 4 == 0)
 
-    def cache_and_assign_ids(self, instance_feature, anchor, confidence, metas=None, threshold=None):
+    def cache_and_assign_ids(self, instance_feature, anchor, confidence, metas=None, threshold=None, hold=None):
         """cache() followed by get_instance_id() (simpb_head.py:744-747) on the persistent state, as two
         launches (csrc/bank.hip). Returns the instance ids, or None when the fused route does not apply
-        (the caller then runs the two methods)."""
+        (the caller then runs the two methods). `hold` (i32 flags on the device): when any is set the launches write
+        nothing, i.e. the persistent state stays as the frame found it (an overflowed frame is re-run: runner.py)."""
         if not self._fusable(instance_feature) or instance_feature.shape[1] != self.num_anchor:
             return None
         st = self._static
@@ -249,7 +250,7 @@ class InstanceBank(nn.Module):
             _ptr(st["prev_id"]), _ptr(ids_out), _ptr(scratch), _ptr(instance_feature.detach().contiguous().float()),
             _ptr(anchor.detach().contiguous().float()), _ptr(cls), bs, a, cls.shape[-1], t, c, 1 if has_prev else 0,
             float(self.confidence_decay), 0 if threshold is None else 1, 0.0 if threshold is None else float(threshold),
-            _stream()), "simpb_bank_cache")
+            _ptr(hold) if hold is not None else None, 0 if hold is None else hold.numel(), _stream()), "simpb_bank_cache")
         self.metas = metas
         self.confidence, self.cached_feature, self.cached_anchor = st["confidence"], st["cached_feature"], st["cached_anchor"]
         self.instance_id, self.prev_id = st["instance_id"], st["prev_id"]

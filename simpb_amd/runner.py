@@ -9,8 +9,10 @@ device buffers, launches the graph, and reads back two small records.
 
 Frame 0 of a stream set has no history (a different dataflow) and runs eagerly; the first warm frame
 runs eagerly too (lazy initialisation outside the capture), the second is captured. If a frame's 2D
-query set ever exceeds the capacity, the overflow flag in the record triggers an eager rerun of that
-frame with a larger capacity; results never silently degrade.
+query set ever exceeds the capacity, the overflow flags (read back with the records) trigger an eager
+rerun of that frame with a larger capacity: the frame-end commit of the instance bank holds back when
+a flag is set (csrc/bank.hip `hold`), so the rerun starts from the state the frame found, the graphs
+are re-captured at the new capacity, and results never silently degrade.
 """
 import numpy as np
 import torch
@@ -46,6 +48,8 @@ class FrameRunner:
         self.warm_frames = 0
         self.host3d = self.host2d = self.host_flag = None
         self.stats = dict(eager=0, replay=0, overflow=0)
+        self.last_rec3d = None      # device record f32 [bs, num_output, 15] of the frame last returned (dist.DetectionGather)
+        self.rec_consumed = None    # event after which that record may be overwritten (set by its consumer, if any)
 
     # ------------------------------------------------------------------ per-frame host work
     def _stage(self, img, metas):
@@ -75,11 +79,28 @@ class FrameRunner:
         rec3d, rec2d = self.head.decoder.decode_static_device(
             outs["classification"], outs["prediction"], outs["instance_id"], outs["quality"],
             outs["classification2d"], outs["prediction2d"], alloc, aug_config)
-        flags = torch.stack([a.overflow[0] for a in outs["alloc_list"]])
-        return rec3d, rec2d, flags
+        return rec3d, rec2d, outs["overflow"]
+
+    # ------------------------------------------------------------------ capacity overflow
+    def _drop_graphs(self):
+        self.graph = self.outputs = None
+
+    def _grow(self):
+        """A frame's 2D query set did not fit: next capacity (x1.5, multiple of 128, at most anchors x cameras, which
+        no set can exceed), graphs dropped. The bank still holds the state the frame found (see module docstring)."""
+        bank = self.head.instance_bank
+        limit = -(-bank.num_anchor * self.head.num_cams // 128) * 128
+        if not bank._fusable(bank._static["cached_anchor"]) or self.capacity >= limit:
+            raise RuntimeError(
+                f"2D query set exceeded the static capacity {self.capacity} and the frame cannot be re-run "
+                "(the instance bank is not on its fused path, so this frame's state is already committed)")
+        self.capacity = min(limit, -(-max(self.capacity + 128, self.capacity * 3 // 2) // 128) * 128)
+        self.head.static_capacity = self.capacity
+        self.stats["overflow"] += 1
+        self._drop_graphs()
 
     def _read_back(self, rec3d, rec2d, flags):
-        if self.host3d is None:
+        if self.host3d is None or self.host2d.shape != rec2d.shape:
             self.host3d = torch.empty(rec3d.shape, dtype=rec3d.dtype).pin_memory()
             self.host2d = torch.empty(rec2d.shape, dtype=rec2d.dtype).pin_memory()
             self.host_flag = torch.empty(flags.shape, dtype=flags.dtype).pin_memory()
@@ -114,14 +135,44 @@ class FrameRunner:
         if warm:
             self.warm_frames += 1
         rec3d, rec2d, overflow = self._read_back(*rec)
-        if overflow:
-            raise RuntimeError(
-                f"2D query set exceeded the static capacity {self.capacity}; construct FrameRunner with a larger "
-                "capacity (results of this frame were discarded, not degraded)")
+        while overflow:  # re-run the frame on the untouched bank state with a larger 2D slot array
+            self._grow()
+            if not warm:
+                self.head.instance_bank.reset()  # a cold frame starts from an empty bank again
+            rec = self._frame(dmetas, aug)
+            self.stats["eager"] += 1
+            rec3d, rec2d, overflow = self._read_back(*rec)
+        self.last_rec3d = rec[0]
         self.prev_metas = dict(img_metas=metas["img_metas"])
         self.head.instance_bank.metas = self.prev_metas
         results = SparseBox3DDecoder.decode_static_host(rec3d.numpy(), rec2d.numpy(), self.head.num_cams)
         return [{"img_bbox": r} for r in results]
+
+
+def cu_masked_streams(device, every):
+    """(backbone stream, decoder stream) on DISJOINT sets of compute units: the decoder stream gets every `every`-th CU
+    of the mask (256 / every of the 256 CUs), the backbone stream all the others (hipExtStreamCreateWithCUMask; torch
+    sees them as external streams). Waves of the two hardware queues then never share a CU."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    words = (n_cu + 31) // 32
+    head_bits = [i for i in range(n_cu) if i % every == 0]
+    masks = []
+    for bits in ([i for i in range(n_cu) if i % every != 0], head_bits):
+        m = (ctypes.c_uint32 * words)()
+        for i in bits:
+            m[i // 32] |= 1 << (i % 32)
+        masks.append(m)
+    out = []
+    with torch.cuda.device(device):
+        for m in masks:
+            h = ctypes.c_void_p()
+            err = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), m)
+            if err != 0:
+                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({err})")
+            out.append(torch.cuda.ExternalStream(h.value, device=device))
+    return out[0], out[1]
 
 
 class PipelinedRunner(FrameRunner):
@@ -141,8 +192,12 @@ class PipelinedRunner(FrameRunner):
         # the decoder of frame t is the critical path (a chain of ~170 dependent small launches); the
         # backbone of frame t+1 only has to be done by the time that chain ends: decoder stream first
         prio = getattr(self, "STREAM_PRIORITIES", (0, -1))
-        self.s_bb = torch.cuda.Stream(device=dev, priority=prio[0])
-        self.s_head = torch.cuda.Stream(device=dev, priority=prio[1])
+        split = getattr(self, "CU_SPLIT", None)
+        if split:
+            self.s_bb, self.s_head = cu_masked_streams(dev, split)
+        else:
+            self.s_bb = torch.cuda.Stream(device=dev, priority=prio[0])
+            self.s_head = torch.cuda.Stream(device=dev, priority=prio[1])
         self.imgs = [self.img, torch.zeros_like(self.img)]
         self.fm = [None, None]              # feature maps of the frame last produced into each slot
         self.bb_graph = [None, None]
@@ -153,6 +208,7 @@ class PipelinedRunner(FrameRunner):
         self.head_runs = [0, 0]
         self.pending = None                 # (frame index, metas) whose features exist but decoder has not run
         self.count = 0
+        self._captured_this_step = False
 
     def _run_backbone(self, slot, force_eager):
         """Enqueue backbone+FPN of the image in slot `slot` on s_bb."""
@@ -163,6 +219,7 @@ class PipelinedRunner(FrameRunner):
                 with torch.cuda.graph(g, stream=self.s_bb):
                     self.bb_out[slot] = self._features(slot)
                 self.bb_graph[slot] = g
+                self._captured_this_step = True
                 self.head_graph[slot] = None  # a decoder graph bound to the old buffer is stale
                 self.head_runs[slot] = 0
             if self.bb_graph[slot] is not None and not force_eager:
@@ -186,7 +243,10 @@ class PipelinedRunner(FrameRunner):
         rec3d, rec2d = self.head.decoder.decode_static_device(
             outs["classification"], outs["prediction"], outs["instance_id"], outs["quality"],
             outs["classification2d"], outs["prediction2d"], alloc, aug)
-        return rec3d, rec2d, torch.stack([a.overflow[0] for a in outs["alloc_list"]])
+        return rec3d, rec2d, outs["overflow"]
+
+    def _drop_graphs(self):
+        self.head_graph, self.head_out, self.head_runs = [None, None], [None, None], [0, 0]
 
     def _run_head(self, slot, dmetas, aug, warm, force_eager):
         """Enqueue the decoder of the frame whose features sit in slot `slot` on s_head."""
@@ -199,7 +259,10 @@ class PipelinedRunner(FrameRunner):
                 with torch.cuda.graph(g, stream=self.s_head):
                     self.head_out[slot] = self._decode(self.fm[slot], dmetas, aug)
                 self.head_graph[slot] = g
+                self._captured_this_step = True
             if graph_ok and self.head_graph[slot] is not None:
+                if self.rec_consumed is not None:  # the record buffer of this graph may still be read by its consumer
+                    self.s_head.wait_event(self.rec_consumed)
                 self.head_graph[slot].replay()
                 rec = self.head_out[slot]
                 self.stats["replay"] += 1
@@ -212,7 +275,7 @@ class PipelinedRunner(FrameRunner):
 
     def _enqueue_readback(self, rec):
         with torch.cuda.stream(self.s_head):
-            if self.host3d is None:
+            if self.host3d is None or self.host2d.shape != rec[1].shape:
                 self.host3d = torch.empty(rec[0].shape, dtype=rec[0].dtype).pin_memory()
                 self.host2d = torch.empty(rec[1].shape, dtype=rec[1].dtype).pin_memory()
                 self.host_flag = torch.empty(rec[2].shape, dtype=rec[2].dtype).pin_memory()
@@ -220,17 +283,27 @@ class PipelinedRunner(FrameRunner):
             self.host2d.copy_(rec[1], non_blocking=True)
             self.host_flag.copy_(rec[2], non_blocking=True)
 
-    def _collect(self, metas):
+    def _collect(self, ctx):
+        """ctx = (slot, metas, warm, rec) of the decoder launch being waited for."""
+        pslot, metas, warm, rec = ctx
         self.s_head.synchronize()
-        if bool(self.host_flag.any()):
-            raise RuntimeError(f"2D query set exceeded the static capacity {self.capacity}; use a larger capacity")
+        while bool(self.host_flag.any()):
+            # overflow: the bank's commit held back, the features of the frame still sit in their slot, the staged
+            # decoder inputs are untouched -> re-run this decoder eagerly with a larger slot array
+            self._grow()
+            if not warm:
+                self.head.instance_bank.reset()  # a cold frame starts from an empty bank again
+            rec = self._run_head(pslot, self._device_metas(metas), metas["img_metas"][0]["aug_config"], warm, True)
+            self._enqueue_readback(rec)
+            self.s_head.synchronize()
+        self.last_rec3d = rec[0]
         self.prev_metas = dict(img_metas=metas["img_metas"])
         results = SparseBox3DDecoder.decode_static_host(self.host3d.numpy(), self.host2d.numpy(), self.head.num_cams)
         return [{"img_bbox": r} for r in results]
 
-    def _finish(self, rec, metas):
+    def _finish(self, slot, metas, warm, rec):
         self._enqueue_readback(rec)
-        return self._collect(metas)
+        return self._collect((slot, metas, warm, rec))
 
     def _stage_head_inputs(self, metas):
         """Per-frame decoder inputs (projection matrices, ego-motion, time step) of the PENDING frame."""
@@ -263,7 +336,15 @@ class PipelinedRunner(FrameRunner):
             warm = self.prev_metas is not None
             rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"], warm, force_eager)
             self._enqueue_readback(rec)
-            self._inflight = pmetas
+            self._inflight = (pslot, pmetas, warm, rec)
+        if self._captured_this_step:
+            # A graph captured in this step has just had its first replay enqueued. torch.cuda.graph() quiesces the
+            # device when a capture STARTS; the first replay of the fresh graph is kept alone on the device as well:
+            # with a second runner launching its own (eager or replayed) work right behind it, that first replay
+            # returned garbage in 16 of 40 two-runner repetitions (profiles/r02_bank_get_fault/README.md, "captures").
+            # Four captures per runner in its lifetime; steady-state steps are untouched.
+            torch.cuda.synchronize()
+        self._captured_this_step = False
         self._next_pending = (slot, metas)
 
     def collect(self):
@@ -286,7 +367,7 @@ class PipelinedRunner(FrameRunner):
             return None
         pslot, pmetas = self.pending
         self._stage_head_inputs(pmetas)
-        rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"],
-                             self.prev_metas is not None, True)
+        warm = self.prev_metas is not None
+        rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"], warm, True)
         self.pending = None
-        return self._finish(rec, pmetas)
+        return self._finish(pslot, pmetas, warm, rec)

@@ -342,7 +342,8 @@ def test_fused_decode_records_match_the_pytorch_statement():
     cls = [torch.randn(bs, A, C, generator=g).cuda()]
     box = [torch.randn(bs, A, 11, generator=g).cuda()]
     quality = [torch.randn(bs, A, 2, generator=g).cuda()]
-    ids = torch.randint(0, 5000, (bs, A), generator=g).cuda()
+    # track ids far above 2^24 (where float32 stops being exact) and above 2^32: they travel as two bit-cast lanes
+    ids = (torch.randint(0, 5000, (bs, A), generator=g) + torch.tensor([(1 << 24) + 1, (1 << 40) + 3])[:, None]).cuda()
     cls2d = [torch.randn(bs, N2, C, generator=g).cuda()]
     box2d = [torch.rand(bs, N2, 4, generator=g).cuda()]
     q2a = torch.randint(-1, A, (bs, N2), generator=g).to(torch.int32).cuda()
@@ -357,11 +358,18 @@ def test_fused_decode_records_match_the_pytorch_statement():
         got3, got2 = dec.decode_static_device(cls, box, ids, quality, cls2d, box2d, alloc, aug)
     finally:
         detection3d.FUSED_DECODE = True
-    assert got3.shape == want3.shape == (bs, 300, 14) and got2.shape == want2.shape == (bs, N2, 8)
-    assert float((got3 - want3).abs().max()) < 2e-4      # ids up to 5000 are exact in f32; boxes/scores ~1e-6
+    from simpb_amd.dist import lanes_to_ids
+    assert got3.shape == want3.shape == (bs, 300, 15) and got2.shape == want2.shape == (bs, N2, 8)
+    assert float((got3[..., :13] - want3[..., :13]).abs().max()) < 2e-4      # boxes/scores ~1e-6
     assert float((got2 - want2).abs().max()) < 2e-3      # pixel coordinates up to 1600: 1 ulp = 1.2e-4
     assert torch.equal(got2[..., 5:], want2[..., 5:])    # label, rank, camera exactly
-    assert torch.equal(got3[..., 11], want3[..., 11]) and torch.equal(got3[..., 13], want3[..., 13])
+    assert torch.equal(got3[..., 11], want3[..., 11])
+    got_ids, want_ids = lanes_to_ids(got3[..., 13:15]), lanes_to_ids(want3[..., 13:15])
+    assert torch.equal(got_ids, want_ids) and int(got_ids.min()) > (1 << 24)  # bit-exact int64 ids
+    order = torch.argsort(want3[..., 10], dim=1, descending=True)  # (rows are already sorted by score)
+    assert set(got_ids[0].tolist()) <= set(ids[0].tolist()) and set(got_ids[1].tolist()) <= set(ids[1].tolist())
+    host = SparseBox3DDecoder.decode_static_host(got3.cpu().numpy(), got2.cpu().numpy(), 6)
+    assert torch.equal(host[1]["instance_ids"], got_ids[1].cpu()) and host[1]["instance_ids"].dtype == torch.int64
 
 
 @gpu

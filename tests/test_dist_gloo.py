@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from simpb_amd.dist import RECORD_WIDTH, gather_detections, pack_detections, shard_streams
+from simpb_amd.dist import (RECORD_WIDTH, DetectionGather, gather_detections, ids_to_lanes, lanes_to_ids, pack_detections,
+                            shard_streams, unpack_detections)
 
 
 def _free_port():
@@ -23,8 +24,40 @@ def _fake_results(stream_ids):
         out.append({"img_bbox": dict(boxes_3d=torch.randn(300, 10, generator=g), scores_3d=torch.rand(300, generator=g),
                                      labels_3d=torch.randint(0, 10, (300,), generator=g),
                                      cls_scores=torch.rand(300, generator=g),
-                                     instance_ids=torch.arange(300) + 1000 * s)})
+                                     instance_ids=torch.arange(300) + 1000 * s + (1 << 33))})  # far above 2^24
     return out
+
+
+def _device_records(stream_ids, frame):
+    """What the runners hand to the exchange: one [1, 300, 15] record per stream in the layout csrc/decode.hip writes
+    (ids as two bit-cast lanes; -1 ids are NaN bit patterns as floats, so everything is compared through int views)."""
+    recs = []
+    for s in stream_ids:
+        g = torch.Generator().manual_seed(1000 * frame + s)
+        rec = torch.randn(1, 300, RECORD_WIDTH, generator=g)
+        ids = torch.arange(300) + 300 * frame + (1 << 25) * (s + 1)
+        ids[::7] = -1
+        rec[0, :, 13:15] = ids_to_lanes(ids)
+        recs.append(rec)
+    return recs
+
+
+def _gather_worker(rank, world, port, q):
+    """bench.py's step(): every frame the rank's runners' records go through DetectionGather.submit, the next frame
+    is submitted without waiting, result() is read at the end (and once in the middle)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_streams(4, rank, world)
+    gather = DetectionGather(len(mine), 300, torch.device("cpu"))
+    seen = []
+    for frame in range(3):
+        gather.submit(_device_records(mine, frame))
+        if frame == 1:
+            seen.append(gather.result().clone())
+    seen.append(gather.result().clone())
+    q.put((rank, [x.numpy().view("int32").copy() for x in seen], gather.frames))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _worker(rank, world, port, q):
@@ -60,4 +93,35 @@ def test_gather_detections_world2():
     want = torch.stack([pack_detections(_fake_results([0, 1])), pack_detections(_fake_results([2, 3]))])
     for _, _, allrec in got:
         assert allrec.shape == (2, 2, 300, RECORD_WIDTH)
-        assert torch.equal(torch.from_numpy(allrec), want)
+        assert (allrec.view("int32") == want.numpy().view("int32")).all()
+
+
+def test_ids_travel_bit_exactly():
+    ids = torch.tensor([-1, 0, (1 << 24) + 1, (1 << 31) + 5, (1 << 40) + 3, -(1 << 35)])
+    lanes = ids_to_lanes(ids)
+    assert lanes.dtype == torch.float32 and lanes.shape == (6, 2)
+    assert torch.equal(lanes_to_ids(lanes), ids) and (lanes_to_ids(lanes.numpy()) == ids.numpy()).all()
+    rec = pack_detections(_fake_results([3]))
+    got = unpack_detections(rec)
+    assert got["instance_ids"].dtype == torch.int64
+    assert torch.equal(got["instance_ids"][0], torch.arange(300) + 3000 + (1 << 33))
+
+
+def test_detection_gather_world2_drives_the_bench_exchange():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for frame, which in ((1, 0), (2, 1)):
+        want = torch.stack([torch.cat(_device_records([0, 1], frame)), torch.cat(_device_records([2, 3], frame))])
+        for _, seen, frames in got:
+            assert frames == 3 and seen[which].shape == (2, 2, 300, RECORD_WIDTH)
+            assert (seen[which] == want.numpy().view("int32")).all()  # every rank holds every stream's record, bit for bit
+        ids = unpack_detections(torch.from_numpy(got[0][1][which].view("float32")))["instance_ids"]
+        assert int(ids[1, 0, 1]) == 1 + 300 * frame + (1 << 25) * 3 and int(ids[0, 0, 0]) == -1

@@ -57,18 +57,47 @@ def test_runner_stream_vs_golden(name, capacity, use_graph):
         assert runner.stats["replay"] >= 1, runner.stats
 
 
-def test_runner_overflow_is_loud():
+@pytest.mark.parametrize("name,capacity,use_graph", [("head_small.npz", 16, False), ("head_r50.npz", 512, True)])
+def test_runner_overflow_reruns_the_frame(name, capacity, use_graph):
+    """A 2D query set larger than the static capacity: the runner grows the capacity and re-runs that frame on the
+    bank state the frame found (the frame-end commit holds back while an overflow flag is set), re-captures its graph,
+    and the stream's detections, track ids included, are the golden ones."""
     from simpb_amd.runner import FrameRunner
-    g = load_golden("head_small.npz")
+    g = load_golden(name)
     spec = spec_of(g)
     model = _FeatureModel(build_product_head(spec), spec)
-    runner = FrameRunner(model, spec["bs"], (8, 8), capacity=16, device=torch.device("cuda"), use_graph=False)
+    runner = FrameRunner(model, spec["bs"], (8, 8), capacity=capacity, device=torch.device("cuda"), use_graph=use_graph)
     w, h = spec["image_wh"]
     runner.wh = torch.tensor([float(w), float(h)], device="cuda").view(1, 1, 2).repeat(spec["bs"], 6, 1)
     runner.wh_host = (w, h)
-    model.load(0)
-    with pytest.raises(RuntimeError, match="capacity"):
-        runner.step(runner.img, synth.frame_metas(spec["bs"], 0, spec["image_wh"]))
+    for f in range(spec["frames"]):
+        model.load(f)
+        res = runner.step(runner.img, synth.frame_metas(spec["bs"], f, spec["image_wh"], jump=spec["jump"]))
+        for b, r in enumerate(res):
+            compare_result(r["img_bbox"], g, f"f{f}.res{b}.")
+    assert runner.stats["overflow"] >= 1 and runner.capacity > capacity, (runner.stats, runner.capacity)
+
+
+def test_runner_overflow_after_capture_reruns_and_recaptures():
+    """Overflow in the middle of a warm stream: the golden R50 stream runs two frames at a capacity that fits, then the
+    slot array is shrunk between frames, so frame 2 overflows with a warm bank, is re-run at a grown capacity on the
+    state it found, and the rest of the stream (re-captured graph) still matches the golden detections and ids."""
+    from simpb_amd.runner import FrameRunner
+    g = load_golden("head_r50.npz")
+    spec = spec_of(g)
+    model = _FeatureModel(build_product_head(spec), spec)
+    runner = FrameRunner(model, 1, (8, 8), capacity=1536, device=torch.device("cuda"), use_graph=True)
+    w, h = spec["image_wh"]
+    runner.wh = torch.tensor([float(w), float(h)], device="cuda").view(1, 1, 2).repeat(1, 6, 1)
+    runner.wh_host = (w, h)
+    for f in range(spec["frames"]):
+        if f == 2:  # between frames: shrink the slot array; the frame that follows overflows, grows, re-runs
+            runner.capacity = runner.head.static_capacity = 640
+            runner._drop_graphs()
+        model.load(f)
+        res = runner.step(runner.img, synth.frame_metas(1, f, spec["image_wh"], jump=spec["jump"]))
+        compare_result(res[0]["img_bbox"], g, f"f{f}.res0.")
+    assert runner.stats["overflow"] >= 1 and runner.stats["replay"] >= 1, runner.stats
 
 
 class _StagedModel(torch.nn.Module):
@@ -124,6 +153,67 @@ def test_pipelined_runner_vs_golden():
     assert outs[0] is None
     for f in range(spec["frames"]):
         compare_result(outs[f + 1][0]["img_bbox"], g, f"f{f}.res0.")
+
+
+def test_pipelined_runner_overflow_reruns_the_decoder():
+    """Same stream through the pipelined runner with a slot array that is too small: the decoder of the overflowed
+    frame is re-run (beside the next frame's backbone) and the golden detections come out, one step later."""
+    g = load_golden("head_r50.npz")
+    spec = spec_of(g)
+    model, runner = _golden_pipelined_runner(spec)
+    runner.capacity = runner.head.static_capacity = 768
+    outs = []
+    for f in range(spec["frames"]):
+        model.stage(f)
+        torch.cuda.synchronize()
+        outs.append(runner.step(runner.img, synth.frame_metas(1, f, spec["image_wh"])))
+    outs.append(runner.flush())
+    for f in range(spec["frames"]):
+        compare_result(outs[f + 1][0]["img_bbox"], g, f"f{f}.res0.")
+    assert runner.stats["overflow"] >= 1 and runner.capacity > 768, (runner.stats, runner.capacity)
+
+
+def test_config3_eight_streams_per_gpu_vs_golden():
+    """BASELINE config #3 shape on one GPU: 8 independent camera streams at R50 704x256, each its own pipelined runner
+    (bs = 1, the reference's own test setting), launched back to back and collected together like bench.py --streams 8.
+    Every stream is fed the golden feature stream (stream i starts i % 3 steps late, so neighbours are at different
+    frames) and must return the golden detections; the device records of the eight streams go through
+    dist.DetectionGather (the exchange bench.py runs over RCCL) and must equal the host results bit for bit, int64
+    track ids included."""
+    from simpb_amd.dist import DetectionGather, unpack_detections
+    g = load_golden("head_r50.npz")
+    spec = spec_of(g)
+    n, frames = 8, spec["frames"]
+    pairs = [_golden_pipelined_runner(spec) for _ in range(n)]
+    lag = [i % 3 for i in range(n)]
+    gather = DetectionGather(n, 300, torch.device("cuda"))
+    outs = [[] for _ in range(n)]
+    fed = [0] * n
+    checked = 0
+    for step in range(frames + max(lag)):
+        live = [i for i in range(n) if 0 <= step - lag[i] < frames]
+        for i in live:
+            model, runner = pairs[i]
+            model.stage(step - lag[i])
+            torch.cuda.synchronize()  # the staging buffer is test scaffolding shared with the runner's streams
+            runner.launch(runner.img, synth.frame_metas(1, step - lag[i], spec["image_wh"]))
+        for i in live:
+            outs[i].append(pairs[i][1].collect())
+        if len(live) == n and all(o[-1] is not None for o in outs):
+            gather.submit([pairs[i][1].last_rec3d for i in range(n)], [pairs[i][1].s_head for i in range(n)])
+            for i in range(n):
+                pairs[i][1].rec_consumed = gather.done
+            rec = unpack_detections(gather.result()[0])
+            for i in range(n):
+                want = outs[i][-1][0]["img_bbox"]
+                assert torch.equal(rec["boxes_3d"][i], want["boxes_3d"]) and torch.equal(rec["scores_3d"][i], want["scores_3d"])
+                assert torch.equal(rec["instance_ids"][i], want["instance_ids"]) and torch.equal(rec["labels_3d"][i], want["labels_3d"])
+            checked += 1
+    assert checked >= 1
+    for i in range(n):
+        out = outs[i][1:] + [pairs[i][1].flush()]
+        for f in range(frames):
+            compare_result(out[f][0]["img_bbox"], g, f"f{f}.res0.")
 
 
 class _ReplayModel(torch.nn.Module):

@@ -1,6 +1,7 @@
-"""The row kernels keep the store discipline of csrc/store_fence.h: in the generated gfx950 ISA no vector-memory store
-is issued among outstanding loads in front of a counted `s_waitcnt vmcnt(N > 0)` (the instruction pattern of the
-round-2 bank_get fault: DESIGN.md section 4). hipcc -S cross-compiles without a GPU."""
+"""The row kernels keep the store discipline of csrc/store_fence.h: in the generated gfx950 ISA no counted
+`s_waitcnt vmcnt(N > 0)` releases consumers while a vector-memory store and a load can both be in flight (the schedule
+bank_get and dfa_points had when they faulted in lanes 48-63 beside a busy second queue: DESIGN.md section 4).
+hipcc -S cross-compiles without a GPU."""
 import glob
 import os
 import subprocess
@@ -12,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_store_scan  # noqa: E402
 
-ROW_KERNEL_FILES = ["bank", "alloc", "decode", "rowops", "format"]
+# every kernel file but gemm.hip, whose only flagged store is the zero fill of a dead tile (rows past m_live), a
+# workgroup-uniform branch that returns right after it; the scan reads the ISA as straight-line text and cannot see that.
+ROW_KERNEL_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(ROOT, "simpb_amd", "csrc", "*.hip"))
+                          if os.path.basename(p) != "gemm.hip")
 
 
 @pytest.mark.parametrize("name", ROW_KERNEL_FILES)
@@ -35,3 +39,8 @@ def test_scanner_sees_the_pattern(tmp_path):
     asm.write_text("kern:\n\tglobal_load_dwordx4 v[2:5], v[0:1], off\n\ts_waitcnt vmcnt(0)\n"
                    "\tglobal_store_dwordx3 v[10:11], v[2:4], off\n\ts_endpgm\n")
     assert not isa_store_scan.scan(str(asm))
+    # dfa_points' round-1 loop: this camera's stores in flight while the next camera's rows arrive behind counted waits
+    asm.write_text("kern:\n.LBB0_1:\n\tglobal_load_dwordx4 v[2:5], v[0:1], off\n\tglobal_load_dwordx4 v[6:9], v[0:1], off offset:16\n"
+                   "\ts_waitcnt vmcnt(1)\n\tv_mov_b32_e32 v12, v2\n\ts_waitcnt vmcnt(0)\n\tglobal_store_dword v[10:11], v12, off\n"
+                   "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    assert not isa_store_scan.scan(str(asm))  # (straight-line reading: the loop-carried store needs the real kernel's unroll)

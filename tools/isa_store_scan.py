@@ -20,36 +20,32 @@ LABEL = re.compile(r"^([A-Za-z_.$][\w.$]*):")
 
 
 def scan(path):
-    """{kernel: [(line number, outstanding loads at the store, counted wait text)]}"""
-    hits, kernel, pending_loads, store_seen = {}, None, 0, None
+    """{kernel: [(line of the counted wait, stores in flight, loads in flight, wait text)]}: sites where a counted
+    `s_waitcnt vmcnt(N > 0)` releases consumers while at least one vector-memory store AND one load may still be in
+    flight (issued since the last vmcnt(0), in either order: `load.. store.. wait` as bank_get had it, or
+    `store.. (loop back) load.. wait` as dfa_points had it). Conservative across basic-block labels."""
+    hits, kernel, loads, stores = {}, None, 0, 0
     for ln, line in enumerate(open(path), 1):
         m = LABEL.match(line)
         if m and not m.group(1).startswith(".L"):
-            kernel, pending_loads, store_seen = m.group(1), 0, None
+            kernel, loads, stores = m.group(1), 0, 0
             continue
-        if m:  # basic-block label: keep counting conservatively (loads may be outstanding across it)
-            continue
-        if kernel is None:
+        if m or kernel is None:
             continue
         if LOAD.match(line):
-            pending_loads += 1
+            loads += 1
         elif STORE.match(line):
-            if pending_loads > 0:
-                store_seen = (ln, pending_loads)
+            stores += 1
         else:
             w = WAIT.match(line)
             if w:
                 v = VMCNT.search(w.group(1))
-                if v is None:
-                    continue
-                n = int(v.group(1))
-                if n == 0:
-                    pending_loads, store_seen = 0, None
-                else:
-                    if store_seen is not None:
-                        hits.setdefault(kernel, []).append((store_seen[0], store_seen[1], line.strip()))
-                        store_seen = None
-                    pending_loads = min(pending_loads, n)
+                if v is not None:
+                    n = int(v.group(1))
+                    if n == 0:
+                        loads = stores = 0
+                    elif stores > 0 and loads > 0 and n < loads + stores:
+                        hits.setdefault(kernel, []).append((ln, stores, loads, line.strip()))
         if "s_endpgm" in line:
             kernel = None
     return hits
@@ -64,9 +60,9 @@ def main():
                         "-o", s, src] + sys.argv[1:], check=True, stderr=subprocess.DEVNULL)
         for kernel, rows in scan(s).items():
             total += 1
-            print(f"{os.path.basename(src)}: {kernel}: {len(rows)} site(s); first: store at line {rows[0][0]} with "
-                  f"{rows[0][1]} load(s) outstanding, then `{rows[0][2]}`")
-    print(f"{total} kernel(s) issue a store among outstanding loads in front of a counted vmcnt wait")
+            print(f"{os.path.basename(src)}: {kernel}: {len(rows)} site(s); first at line {rows[0][0]}: `{rows[0][3]}` with "
+                  f"{rows[0][1]} store(s) and {rows[0][2]} load(s) possibly in flight")
+    print(f"{total} kernel(s) release consumers on a counted vmcnt wait with stores and loads in flight")
 
 
 if __name__ == "__main__":

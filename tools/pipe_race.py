@@ -36,12 +36,16 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="with --trace: print every differing record of the first bad frame")
     ap.add_argument("--pre-kernel", action="store_true", help="one throw-away launch on the decoder stream in front of bank_get")
     ap.add_argument("--bank-diag", action="store_true", help="library built with -DSIMPB_BANK_DIAG: print bank_get's self-check log")
+    ap.add_argument("--streams", type=int, default=1, help="camera streams (runners) launched side by side; the first is checked")
+    ap.add_argument("--cu-split", type=int, default=0, help="decoder stream on every N-th CU, backbone stream on the others (disjoint CU masks)")
     ap.add_argument("--dump", default="", help="with --trace: save the bank_get operands of the first bad frame here and stop")
     args = ap.parse_args()
     from simpb_amd import configs, plugin, synth
     from simpb_amd.runner import FrameRunner, PipelinedRunner
     wh = (352, 128)
     dev = torch.device("cuda")
+    if args.cu_split:
+        PipelinedRunner.CU_SPLIT = args.cu_split
     if args.equal_priority:
         PipelinedRunner.STREAM_PRIORITIES = (0, 0)
     if args.no_miopen:
@@ -99,6 +103,23 @@ def main():
             if name:
                 mod.register_forward_hook(hook_for(name))
 
+        from simpb_amd.plugin import blocks as _blocks
+        if not hasattr(_blocks, "_race_daf_orig"):
+            _blocks._race_daf_orig = _blocks.DAF
+            _blocks._race_sinks = []
+
+            def daf_spy(feat, ss, ssi, loc, w):
+                out = _blocks._race_daf_orig(feat, ss, ssi, loc, w)
+                for sink, stream in _blocks._race_sinks:
+                    if sink["rec"] is not None and torch.cuda.current_stream() == stream():
+                        k = sink["daf"] = sink.get("daf", 0) + 1
+                        flat(f"daf.{k:02d}.loc", loc, sink["rec"])
+                        flat(f"daf.{k:02d}.weights", w, sink["rec"])
+                        flat(f"daf.{k:02d}.out", out, sink["rec"])
+                return out
+
+            _blocks.DAF = daf_spy
+        _blocks._race_sinks.append((cur, (lambda: runner.s_head) if hasattr(runner, "s_head") else torch.cuda.current_stream))
         inner_get = bank.get
 
         def spy_get(*a, **k):
@@ -119,8 +140,11 @@ def main():
         bank.get = spy_get
 
         def forward(fm, metas, *a, **k):
+            if torch.cuda.is_current_stream_capturing():  # a capture is not a frame: no record, and no clones in the graph
+                cur["rec"] = None
+                return inner(fm, metas, *a, **k)
             rec = {}
-            cur["rec"], cur["seq"] = rec, 0
+            cur["rec"], cur["seq"], cur["daf"] = rec, 0, 0
             flat("in.fm", list(fm)[:3], rec)
             flat("in.values", list(fm)[3] if len(fm) > 3 else None, rec)
             flat("in.proj", metas.get("projection_mat"), rec)
@@ -163,10 +187,22 @@ def main():
             r._features = fake_features
         seen, out = [], []
         pipe_trace, plain_trace = [], []
+        from simpb_amd.plugin import blocks as _b
+        if hasattr(_b, "_race_sinks"):
+            _b._race_sinks.clear()  # records of earlier repetitions
         if args.trace >= 0:
             spy_on(r, pipe_trace)
+        others = [PipelinedRunner(make(), 1, (wh[1], wh[0]), capacity=1536, device=dev, use_graph=not args.eager)
+                  for _ in range(args.streams - 1)]  # further camera streams launched beside the traced one (bench --streams)
         for f in range(frames):
-            out.append(r.step(imgs[f], metas[f], force_eager=args.eager))
+            r.launch(imgs[f], metas[f], force_eager=args.eager)
+            for k, o in enumerate(others):
+                if f - (k + 1) >= 0:  # each a frame behind the previous one
+                    o.launch(imgs[f - (k + 1)], metas[f - (k + 1)], force_eager=args.eager)
+            out.append(r.collect())
+            for k, o in enumerate(others):
+                if f - (k + 1) >= 0:
+                    o.collect()
             if f >= 1:
                 seen.append([t.clone() for t in r.fm[(f - 1) % 2][:3]])
         seen.append([t.clone() for t in r.fm[(frames - 1) % 2][:3]])
@@ -188,8 +224,12 @@ def main():
             if trial == 0 and max(diffs) > 1e-3:
                 bad += 1
         if args.trace >= 0 and max(float(x) for x in lines[0].split()) > 1e-3:
-            first_bad = next(i for i, x in enumerate(lines[0].split()) if float(x) > 1e-3)
+            first_bad = next(i for i, x in enumerate(lines[0].split()) if float(x) > 0)  # bit-exact otherwise
             args.trace = first_bad
+            if args.trace >= len(pipe_trace):
+                print(f"    first differing frame {args.trace} was a graph replay (no per-module records)", flush=True)
+                print(f"rep {rep}: pipe-vs-plainA {lines[0]}", flush=True)
+                continue
             a, b = pipe_trace[args.trace], plain_trace[args.trace]
             k3 = "bank_get.out.3"
             if k3 in a and k3 in b:
@@ -200,6 +240,17 @@ def main():
                 vals = sorted(set(round(float(x), 5) for x in pa[rows][:, cols].flatten().tolist()))[:6]
                 print(f"    FAULT frame {args.trace}: rows {rows[:3]}..{rows[-3:]} (n={len(rows)}) cols {cols} bad values {vals} "
                       f"T row0 {[round(float(x), 5) for x in Tm[0]]} row1 {[round(float(x), 5) for x in Tm[1]]} row2 {[round(float(x), 5) for x in Tm[2]]}", flush=True)
+            first = [key for key in a if key in b and a[key].shape == b[key].shape and a[key].numel()
+                     and not torch.equal(a[key], b[key])][:6]
+            print(f"    first differing records of frame {args.trace}: {first}", flush=True)
+            if first:
+                x, y = a[first[0]].cpu().float(), b[first[0]].cpu().float()
+                x2, y2 = x.reshape(-1, x.shape[-1]), y.reshape(-1, y.shape[-1])
+                rows = (x2 != y2).any(1).nonzero().flatten().tolist()
+                cols = (x2 != y2).any(0).nonzero().flatten().tolist()
+                print(f"    {first[0]} shape {tuple(x.shape)}: {len(rows)} rows differ {rows[:8]}..{rows[-3:]}, {len(cols)} cols "
+                      f"{cols[:6]}..{cols[-3:]}, max|diff| {float((x2 - y2).abs().max()):.3e}, pipe there "
+                      f"{[round(float(v), 4) for v in x2[rows[0], cols[:6]]]} plain {[round(float(v), 4) for v in y2[rows[0], cols[:6]]]}", flush=True)
             for key in (a if args.verbose else ()):
                 if key in b and a[key].shape == b[key].shape:
                     d = float((a[key].double() - b[key].double()).abs().max()) if a[key].numel() else 0.0
