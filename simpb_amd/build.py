@@ -39,15 +39,20 @@ def needs_build():
     return open(STAMP).read().strip() != source_hash()
 
 
-def build_extension(force=False, verbose=False, jobs=None):
-    if not force and not needs_build():
+def build_extension(force=False, verbose=False, jobs=None, extra_flags=(), out=None):
+    """Compile csrc/*.hip into the in-tree library. `extra_flags` + `out` build a VARIANT next to it instead (its own
+    object directory, no stamp): used by tools/daf_stress.py to rebuild the kernels with the single-instruction FP16
+    matrix step (-DSIMPB_MFMA_F16_K16=1, csrc/mfma_f16.h) for the interference measurement."""
+    variant = out is not None
+    if not variant and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(OBJ, exist_ok=True)
+    obj_dir = OBJ if not variant else os.path.join(os.path.dirname(os.path.abspath(out)), "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
 
     def compile_one(src):
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -55,13 +60,15 @@ def build_extension(force=False, verbose=False, jobs=None):
 
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
         objects = list(pool.map(compile_one, sources()))
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objects
+    target = LIB if not variant else os.path.abspath(out)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-o", target] + objects
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.run(link, check=True)
-    with open(STAMP, "w") as f:
-        f.write(source_hash())
-    return LIB
+    if not variant:
+        with open(STAMP, "w") as f:
+            f.write(source_hash())
+    return target
 
 
 if __name__ == "__main__":

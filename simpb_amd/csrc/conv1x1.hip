@@ -17,6 +17,7 @@
 #include <hip/hip_fp16.h>
 #include <type_traits>
 #include "../../include/simpb_hip.h"
+#include "mfma_f16.h"
 
 extern "C" int simpb_check_launch(void);
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         const h16x8 b = *reinterpret_cast<const h16x8*>(&s_b[(n * 32 + r32) * LDH + 16 * ks + 8 * kb]);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[n], 0, 0, 0);
+        acc[n] = simpb::mfma_32x32x16_f16(a, b, acc[n]);
       }
     }
   };

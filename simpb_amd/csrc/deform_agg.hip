@@ -114,12 +114,6 @@ __global__ __launch_bounds__(kThreads) void daf_fwd_rows(
                    x1, y1, ld_off);
         wg1 = wrow[((size_t)i1 * L + lvl) * G];
       }
-      // Both samples' rows (8 x 1 KiB per wave) and weights are requested; wait for ALL of them, then do the arithmetic.
-      // Round 2: with counted waits (accumulate sample 0 while sample 1's rows are still arriving) this kernel, like
-      // bank_get and dfa_points, occasionally produced a wrong partial sum in lanes 48-63 of one wave when another
-      // hardware queue kept the chip busy (store_fence.h); a full wait costs nothing measurable here, the other
-      // waves of the CU cover the latency.
-      simpb::loads_retired();
       accumulate(acc, t0, wg0);
       if (i1 >= 0) accumulate(acc, t1, wg1);
     }

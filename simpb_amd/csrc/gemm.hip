@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "../../include/simpb_hip.h"
+#include "mfma_f16.h"
 
 extern "C" int simpb_check_launch(void);
 
@@ -359,10 +360,10 @@ __global__ __launch_bounds__(kThreads) void gemm_f16x3_kernel(GemmLaunch L) {
     const h16x8 al = *reinterpret_cast<const h16x8*>(&s_xl[(buf * BM + r32) * LDH + off]);
     const h16x8 bh = *reinterpret_cast<const h16x8*>(&s_wh[(buf * BN + wn * 32 + r32) * LDH + off]);
     const h16x8 bl = *reinterpret_cast<const h16x8*>(&s_wl[(buf * BN + wn * 32 + r32) * LDH + off]);
-    act = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, act, 0, 0, 0);
-    acs = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acs, 0, 0, 0);
-    acs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acs, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    act = simpb::mfma_32x32x16_f16(al, bl, act);
+    acs = simpb::mfma_32x32x16_f16(al, bh, acs);
+    acs = simpb::mfma_32x32x16_f16(ah, bl, acs);
+    acc = simpb::mfma_32x32x16_f16(ah, bh, acc);
   };
 
   static_for<0, DEPTH>([&](auto d) __attribute__((always_inline)) { fetch(d, decltype(d)::value); });

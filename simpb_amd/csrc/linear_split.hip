@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "../../include/simpb_hip.h"
+#include "mfma_f16.h"
 
 extern "C" int simpb_check_launch(void);
 
@@ -115,9 +116,9 @@ __global__ __launch_bounds__(kThreads) void linear_f16x3_kernel(float* __restric
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          acs[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acs[m][n], 0, 0, 0);
-          acs[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acs[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+          acs[m][n] = simpb::mfma_32x32x16_f16(al[m], bh[n], acs[m][n]);
+          acs[m][n] = simpb::mfma_32x32x16_f16(ah[m], bl[n], acs[m][n]);
+          acc[m][n] = simpb::mfma_32x32x16_f16(ah[m], bh[n], acc[m][n]);
         }
     }
   }

@@ -149,32 +149,6 @@ class FrameRunner:
         return [{"img_bbox": r} for r in results]
 
 
-def cu_masked_streams(device, every):
-    """(backbone stream, decoder stream) on DISJOINT sets of compute units: the decoder stream gets every `every`-th CU
-    of the mask (256 / every of the 256 CUs), the backbone stream all the others (hipExtStreamCreateWithCUMask; torch
-    sees them as external streams). Waves of the two hardware queues then never share a CU."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-    words = (n_cu + 31) // 32
-    head_bits = [i for i in range(n_cu) if i % every == 0]
-    masks = []
-    for bits in ([i for i in range(n_cu) if i % every != 0], head_bits):
-        m = (ctypes.c_uint32 * words)()
-        for i in bits:
-            m[i // 32] |= 1 << (i % 32)
-        masks.append(m)
-    out = []
-    with torch.cuda.device(device):
-        for m in masks:
-            h = ctypes.c_void_p()
-            err = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), m)
-            if err != 0:
-                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({err})")
-            out.append(torch.cuda.ExternalStream(h.value, device=device))
-    return out[0], out[1]
-
-
 class PipelinedRunner(FrameRunner):
     """FrameRunner with the backbone of frame t+1 overlapped with the decoder of frame t.
 
@@ -192,12 +166,8 @@ class PipelinedRunner(FrameRunner):
         # the decoder of frame t is the critical path (a chain of ~170 dependent small launches); the
         # backbone of frame t+1 only has to be done by the time that chain ends: decoder stream first
         prio = getattr(self, "STREAM_PRIORITIES", (0, -1))
-        split = getattr(self, "CU_SPLIT", None)
-        if split:
-            self.s_bb, self.s_head = cu_masked_streams(dev, split)
-        else:
-            self.s_bb = torch.cuda.Stream(device=dev, priority=prio[0])
-            self.s_head = torch.cuda.Stream(device=dev, priority=prio[1])
+        self.s_bb = torch.cuda.Stream(device=dev, priority=prio[0])
+        self.s_head = torch.cuda.Stream(device=dev, priority=prio[1])
         self.imgs = [self.img, torch.zeros_like(self.img)]
         self.fm = [None, None]              # feature maps of the frame last produced into each slot
         self.bb_graph = [None, None]
@@ -208,7 +178,6 @@ class PipelinedRunner(FrameRunner):
         self.head_runs = [0, 0]
         self.pending = None                 # (frame index, metas) whose features exist but decoder has not run
         self.count = 0
-        self._captured_this_step = False
 
     def _run_backbone(self, slot, force_eager):
         """Enqueue backbone+FPN of the image in slot `slot` on s_bb."""
@@ -219,7 +188,6 @@ class PipelinedRunner(FrameRunner):
                 with torch.cuda.graph(g, stream=self.s_bb):
                     self.bb_out[slot] = self._features(slot)
                 self.bb_graph[slot] = g
-                self._captured_this_step = True
                 self.head_graph[slot] = None  # a decoder graph bound to the old buffer is stale
                 self.head_runs[slot] = 0
             if self.bb_graph[slot] is not None and not force_eager:
@@ -259,7 +227,6 @@ class PipelinedRunner(FrameRunner):
                 with torch.cuda.graph(g, stream=self.s_head):
                     self.head_out[slot] = self._decode(self.fm[slot], dmetas, aug)
                 self.head_graph[slot] = g
-                self._captured_this_step = True
             if graph_ok and self.head_graph[slot] is not None:
                 if self.rec_consumed is not None:  # the record buffer of this graph may still be read by its consumer
                     self.s_head.wait_event(self.rec_consumed)
@@ -337,14 +304,6 @@ class PipelinedRunner(FrameRunner):
             rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"], warm, force_eager)
             self._enqueue_readback(rec)
             self._inflight = (pslot, pmetas, warm, rec)
-        if self._captured_this_step:
-            # A graph captured in this step has just had its first replay enqueued. torch.cuda.graph() quiesces the
-            # device when a capture STARTS; the first replay of the fresh graph is kept alone on the device as well:
-            # with a second runner launching its own (eager or replayed) work right behind it, that first replay
-            # returned garbage in 16 of 40 two-runner repetitions (profiles/r02_bank_get_fault/README.md, "captures").
-            # Four captures per runner in its lifetime; steady-state steps are untouched.
-            torch.cuda.synchronize()
-        self._captured_this_step = False
         self._next_pending = (slot, metas)
 
     def collect(self):

@@ -1,0 +1,116 @@
+"""Stand-alone stress of the 3D deformable-aggregation kernel beside a busy second stream (round 2: the kernel gives a wrong
+partial sum in channels 192-255 of an anchor now and then when another hardware queue keeps the chip busy).
+
+One stream launches daf_fwd_rows over and over on fixed operands of the shipped shapes and compares each output with the
+output of the same launch on an idle device; a second stream loops a co-runner kernel. Reports faulty launches, rows and
+the channel blocks that differ.
+
+    python tools/daf_stress.py [--k16] [--co conv1x1|linear_split|conv3x3|linear_f32|matmul|copy|bias_act|format|none]
+                               [--launches N] [--cu-split K]
+--k16 rebuilds the library (into gpurun_out/k16/) with the single-instruction FP16 matrix step v_mfma_f32_32x32x16_f16
+(-DSIMPB_MFMA_F16_K16=1, csrc/mfma_f16.h) instead of the product's two v_mfma_f32_32x32x8f16 steps, and runs with that.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--k16", action="store_true")
+    ap.add_argument("--co", default="conv1x1")
+    ap.add_argument("--launches", type=int, default=3000)
+    ap.add_argument("--cu-split", type=int, default=0)
+    ap.add_argument("--anchors", type=int, default=900)
+    args = ap.parse_args()
+    import simpb_amd._lib as L
+    if args.k16:
+        from simpb_amd import build
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out", "k16"), exist_ok=True)
+        L.LIB = build.build_extension(extra_flags=["-DSIMPB_MFMA_F16_K16=1"],
+                                      out=os.path.join(root, "gpurun_out", "k16", "libsimpb_hip_k16.so"))
+    from simpb_amd.plugin import ops
+    from _streams import cu_masked_streams
+    dev = torch.device("cuda")
+    L.lib()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    shapes = [(64, 176), (32, 88), (16, 44), (8, 22)]
+    maps = [torch.randn(1, 6, 256, h, w, generator=g).cuda() for h, w in shapes]
+    col, ss, ssi = ops.feature_maps_format(maps)
+    A, P, K, Lv, G = args.anchors, 13, 6, 4, 8
+    loc = (torch.rand(1, A, P, K, 2, generator=g) * 1.6 - 0.3).cuda()
+    w = torch.softmax(torch.randn(1, A, P * K * Lv, G, generator=g), dim=2).reshape(1, A, P, K, Lv, G).permute(0, 1, 2, 3, 4, 5).contiguous().cuda()
+    ss32, ssi32 = ss.int().contiguous(), ssi.int().contiguous()
+
+    def daf():
+        return ops.deformable_aggregation_function(col, ss32, ssi32, loc, w)
+
+    ref = daf()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        assert torch.equal(daf(), ref), "not deterministic on an idle device"
+    if args.cu_split:
+        s_co, s_daf = cu_masked_streams(dev, args.cu_split)
+    else:
+        s_co, s_daf = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+    import torch.nn.functional as F
+    cx = torch.randn(6, 256, 64, 176, device=dev).half().contiguous(memory_format=torch.channels_last)
+    cw3 = (torch.randn(256, 256, 3, 3, device=dev) * 0.02).half().contiguous(memory_format=torch.channels_last)
+    cw1 = (torch.randn(256, 256, 1, 1, device=dev) * 0.02).half()
+    cb = torch.zeros(256, device=dev).half()
+    big = torch.randn(23 * 1024 * 1024, device=dev)
+    mm = torch.randn(4096, 4096, device=dev)
+    vx = torch.randn(6, 14960, 256, device=dev)
+    vw = torch.randn(256, 256, device=dev) * 0.05
+    vb = torch.zeros(256, device=dev)
+    lv = [torch.randn(6, 256, h, w, device=dev).half().contiguous(memory_format=torch.channels_last) for h, w in shapes]
+
+    def co():
+        if args.co == "conv1x1":
+            ops.conv1x1_nhwc(cx, cw1, cb, None, True, 1)
+        elif args.co == "conv3x3":
+            F.conv2d(cx, cw3, None, padding=1)
+        elif args.co == "copy":
+            big.clone()
+        elif args.co == "matmul":
+            mm @ mm
+        elif args.co == "linear_split":
+            ops.linear_split(vx, vw, vb)
+        elif args.co == "linear_f32":
+            ops.linear_f32(vx, vw, vb)
+        elif args.co == "bias_act":
+            ops.bias_act_(cx, cb, None, True)
+        elif args.co == "format":
+            ops.format_tokens(lv, 1, 6)
+        elif args.co != "none":
+            raise SystemExit("unknown --co")
+
+    bad_launch = torch.zeros((), dtype=torch.long, device=dev)
+    bad_rows = torch.zeros((), dtype=torch.long, device=dev)
+    blocks = torch.zeros(4, dtype=torch.long, device=dev)
+    torch.cuda.synchronize()
+    for it in range(args.launches):
+        with torch.cuda.stream(s_co):
+            for _ in range(3):
+                co()
+        with torch.cuda.stream(s_daf):
+            out = daf()
+            d = (out != ref)
+            rows = d.any(-1).sum()
+            bad_rows += rows
+            bad_launch += (rows > 0).long()
+            blocks += d.reshape(-1, 4, 64).any(-1).sum(0)
+        if it % 200 == 199:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    print(f"co={args.co} fp16_matrix_step={'1 x 32x32x16' if args.k16 else '2 x 32x32x8'} cu_split={args.cu_split}: {int(bad_launch)} faulty launches of {args.launches}, "
+          f"{int(bad_rows)} rows; faulty rows by channel block [0-63, 64-127, 128-191, 192-255]: {blocks.tolist()}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -38,14 +38,13 @@ def main():
     ap.add_argument("--bank-diag", action="store_true", help="library built with -DSIMPB_BANK_DIAG: print bank_get's self-check log")
     ap.add_argument("--streams", type=int, default=1, help="camera streams (runners) launched side by side; the first is checked")
     ap.add_argument("--cu-split", type=int, default=0, help="decoder stream on every N-th CU, backbone stream on the others (disjoint CU masks)")
+    ap.add_argument("--dummy-kind", default="matmul", help="with --dummy-backbone: matmul | conv3x3 | conv1x1 | value_proj | format | copy | none")
     ap.add_argument("--dump", default="", help="with --trace: save the bank_get operands of the first bad frame here and stop")
     args = ap.parse_args()
     from simpb_amd import configs, plugin, synth
     from simpb_amd.runner import FrameRunner, PipelinedRunner
     wh = (352, 128)
     dev = torch.device("cuda")
-    if args.cu_split:
-        PipelinedRunner.CU_SPLIT = args.cu_split
     if args.equal_priority:
         PipelinedRunner.STREAM_PRIORITIES = (0, 0)
     if args.no_miopen:
@@ -166,6 +165,9 @@ def main():
     bad = 0
     for rep in range(args.reps):
         r = PipelinedRunner(make(), 1, (wh[1], wh[0]), capacity=1536, device=dev, use_graph=not args.eager)
+        if args.cu_split:
+            from _streams import cu_masked_streams
+            r.s_bb, r.s_head = cu_masked_streams(dev, args.cu_split)
         if args.one_stream:
             r.s_bb = r.s_head
         if args.dummy_backbone:
@@ -176,10 +178,44 @@ def main():
             load_a = torch.randn(4096, 4096, device=dev)
             state = {"f": 0}
 
+            import torch.nn.functional as F
+            from simpb_amd.plugin import ops as _ops
+            kind = args.dummy_kind
+            cx = torch.randn(6, 256, 64, 176, device=dev).half().contiguous(memory_format=torch.channels_last)
+            cw3 = (torch.randn(256, 256, 3, 3, device=dev) * 0.02).half().contiguous(memory_format=torch.channels_last)
+            cw1 = (torch.randn(256, 256, 1, 1, device=dev) * 0.02).half()
+            cb = torch.zeros(256, device=dev).half()
+            lv = [torch.randn(6, 256, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
+                  for h, w in ((32, 88), (16, 44), (8, 22), (4, 11))] if wh == (352, 128) else None
+            big = torch.randn(23 * 1024 * 1024, device=dev)
+
+            def load(pre_fm):
+                """One kernel type on the backbone stream, sized to last about as long as a decoder."""
+                if kind == "matmul":
+                    for _ in range(12):
+                        load_a @ load_a
+                elif kind == "conv3x3":
+                    for _ in range(24):
+                        F.conv2d(cx, cw3, None, padding=1)
+                elif kind == "conv1x1":
+                    for _ in range(60):
+                        _ops.conv1x1_nhwc(cx, cw1, cb, None, True, 1)
+                elif kind == "value_proj":
+                    for _ in range(6):
+                        r.head.precompute_values(pre_fm)
+                elif kind == "format":
+                    for _ in range(40):
+                        _ops.format_tokens(lv, 1, 6)
+                elif kind == "copy":
+                    for _ in range(30):
+                        big.clone()
+                elif kind != "none":
+                    raise SystemExit(f"unknown --dummy-kind {kind}")
+
             def fake_features(slot, pre=pre, state=state, load_a=load_a, r=r):
-                for _ in range(12):
-                    load_a @ load_a
-                fm = [t.clone() for t in pre[state["f"] % frames]]
+                load(pre[state["f"] % frames])
+                src = pre[state["f"] % frames]
+                fm = [src[0].clone(), pre[0][1], pre[0][2]]  # ONE pair of (H, W, start) tables (validated once, on the host)
                 state["f"] += 1
                 fm.append(r.head.precompute_values(fm))
                 return fm
@@ -251,6 +287,22 @@ def main():
                 print(f"    {first[0]} shape {tuple(x.shape)}: {len(rows)} rows differ {rows[:8]}..{rows[-3:]}, {len(cols)} cols "
                       f"{cols[:6]}..{cols[-3:]}, max|diff| {float((x2 - y2).abs().max()):.3e}, pipe there "
                       f"{[round(float(v), 4) for v in x2[rows[0], cols[:6]]]} plain {[round(float(v), 4) for v in y2[rows[0], cols[:6]]]}", flush=True)
+            if first and first[0].startswith("daf.") and first[0].endswith(".out"):
+                # is the wrong segment an OLD value of the same addresses (a lost store / stale line) or a new wrong value?
+                x, y = a[first[0]].cpu()[0], b[first[0]].cpu()[0]
+                rows = (x != y).any(1).nonzero().flatten().tolist()
+                cols = (x[rows[0]] != y[rows[0]]).nonzero().flatten()
+                seg = x[rows[0]][cols]
+                cands = []
+                for fi in range(max(0, args.trace - 2), args.trace + 1):
+                    for k2, v2 in pipe_trace[fi].items():
+                        if k2.startswith("daf.") and k2.endswith(".out") and not (fi == args.trace and k2 == first[0]):
+                            cands.append((fi, k2, v2.cpu()[0]))
+                hits = [(fi, k2) for fi, k2, v2 in cands if torch.equal(v2[rows[0]][cols], seg)]
+                near = sorted(((float((v2[rows[0]][cols] - seg).abs().max()), fi, k2) for fi, k2, v2 in cands))[:3]
+                print(f"    wrong segment row {rows[0]} cols {int(cols[0])}..{int(cols[-1])}: identical to an earlier DAF output at the same "
+                      f"place: {hits}; nearest earlier outputs (max|diff|, frame, record): {near}; |pipe-plain| there "
+                      f"{float((seg - y[rows[0]][cols]).abs().max()):.3e}", flush=True)
             for key in (a if args.verbose else ()):
                 if key in b and a[key].shape == b[key].shape:
                     d = float((a[key].double() - b[key].double()).abs().max()) if a[key].numel() else 0.0
