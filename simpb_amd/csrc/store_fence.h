@@ -1,15 +1,13 @@
 // Store discipline of the small row kernels (bank, allocation tables, decode records, anchor projection).
 //
-// Finding of round 2 ("the eager two-stream fault"; data under profiles/r02_bank_get_fault/):
-// bank_get_kernel, as hipcc scheduled it, issued the store of its pass-through columns while seven loads were
-// still outstanding and then consumed the load results behind COUNTED waits (s_waitcnt vmcnt(5)/(3)/(2)/(1), which
-// rely on that store retiring in issue order with the loads). Beside a busy second hardware queue (eager backbone
-// convolutions) about 1 launch in 100 then evaluated one multiply-add of lanes 48-63 of ONE wave with an operand
-// read as zero (the last quarter-wave pass; the registers themselves held the right values before and after: the
-// kernel's own self-check build logged them). The same arithmetic with every load retired before the first store
-// (0 faults in 100 repetitions against 17 for the original, same box, same session) does not fault.
-// Rule: results into registers, every load retired, THEN the stores; tools/isa_store_scan.py (a CPU test) checks the
-// generated ISA for stores issued among outstanding loads in front of a counted wait.
+// Round 2 ("the two-stream fault"): while a kernel built on v_mfma_f32_32x32x16_f16 ran on another
+// stream, vector arithmetic of these kernels went wrong in lanes 48-63 of a wave now and then. The cause was that
+// instruction (csrc/mfma_f16.h no longer issues it); the kernels that were hit first and most (bank_get: 1 launch in 100,
+// dfa_points) were the ones whose schedule had a vector store in flight while COUNTED waits (s_waitcnt vmcnt(N > 0))
+// released the consumers of load results, and the same arithmetic with every load retired before it ran clean in the
+// same session (profiles/r02_bank_get_fault/). The row kernels therefore keep this shape: operands into registers, every
+// load retired, arithmetic, results pinned, every load retired, stores. Hardening, checked on the generated ISA by
+// tools/isa_store_scan.py (a CPU test); it costs nothing measurable in kernels of a few microseconds.
 #pragma once
 #include <hip/hip_runtime.h>
 
