@@ -7,8 +7,9 @@ HBM before the timed region; weights are procedural random-init of the shipped a
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job frames/s,
-`roofline` for the 3D deformable-aggregation kernel (HIP events around every launch inside the
-timed region, algorithmic bytes per SURVEY.md §8d), `cpu_baseline` = the oracle (CPU restatement
+`roofline` for the 3D deformable-aggregation kernel (HIP events on the launch stream around each of its
+launches in a few instrumented frames run right after the timed region -- event nodes cannot be read back
+from inside a replayed graph; algorithmic bytes per SURVEY.md §8d), `cpu_baseline` = the oracle (CPU restatement
 of the reference) timed on the host cores for a bounded sample (rank 0, N = 1 only).
 """
 import argparse
@@ -58,8 +59,8 @@ def parse():
 
 class KernelMeter:
     """Roofline leg. Durations come from HIP event pairs the library records on the launch stream
-    directly around each sampler launch (simpb_timing_*, include/simpb_hip.h), for every launch of
-    the timed region. The wrappers here only remember each launch's shapes (and the DAF sampling
+    directly around each sampler launch (simpb_timing_*, include/simpb_hip.h), for every sampler launch of
+    the instrumented frames that follow the timed region. The wrappers here only remember each launch's shapes (and the DAF sampling
     locations, to count valid triples afterwards) so algorithmic bytes can be computed."""
 
     DAF, MSDA = 1, 2
@@ -185,7 +186,8 @@ def cpu_baseline(args):
             times.append(time.perf_counter() - t0)
     warm = times[1:] or times
     return dict(value=len(warm) / sum(warm), unit="frames/s", cores=cores, kind="port",
-                sample=f"{len(warm)} warm frame(s) after 1 cold, bs=1, oracle head fp32 + PyTorch CPU ResNet{args.depth}+FPN fp32, "
+                sample=f"bounded sample (not BASELINE.md's 50-frame protocol: a frame takes ~1 s here): {len(warm)} warm frame(s) "
+                       f"after 1 cold, bs=1, oracle head fp32 + PyTorch CPU ResNet{args.depth}+FPN fp32, "
                        f"torch threads={cores}")
 
 
@@ -293,27 +295,40 @@ def main():
         mode = dict(runner.stats, hipgraph=not args.eager, capacity_2d=args.capacity,
                     pipelined_backbone=pipelined)
         def pmc_traffic(kernel):
-            """HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside
-            this process); None when no profile of this kernel is committed."""
+            """HBM-side bytes per launch of `kernel` from the newest committed PMC passes (profiles/r*_sampler_traffic.json;
+            rocprofv3 --pmc cannot run inside this process: tools/profile_round.py takes them with this same command),
+            with the file they came from; (None, None) when no profile of this kernel is committed."""
             import glob
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sampler_traffic.json")), reverse=True):
                 try:
-                    return json.load(open(path))["kernels"][kernel]["traffic_bytes_per_launch"]
+                    return json.load(open(path))["kernels"][kernel]["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
                 except (KeyError, ValueError):
                     continue
-            return None
+            return None, None
 
-        def roofline(k, note):
+        feat_mb = 6 * sum((args.image_wh[1] // s) * (args.image_wh[0] // s) for s in (4, 8, 16, 32)) * 256 * 4 / 1e6
+        in_cache = feat_mb * 1e6 < 256 * 2 ** 20
+
+        def roofline(k, what):
             ach = k["nbytes"] / k["secs"] / 1e9
+            traffic, src = pmc_traffic(k["kernel"])
             r = dict(kernel=k["kernel"], bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
-                     frac=ach / HBM_PEAK_GBPS, traffic=pmc_traffic(k["kernel"]), avg_us=k["secs"] * 1e6, algorithmic_MB=k["nbytes"] / 1e6,
-                     launches=k["launches"], note=note)
+                     frac=ach / HBM_PEAK_GBPS, traffic=traffic, avg_us=k["secs"] * 1e6, algorithmic_MB=k["nbytes"] / 1e6,
+                     launches=k["launches"],
+                     regime="infinity-cache" if in_cache else "hbm",
+                     hbm_side_GBps=(traffic / k["secs"] / 1e9) if traffic else None,
+                     hbm_side_frac=(traffic / k["secs"] / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                     traffic_source=src,
+                     note=f"{what}; achieved = algorithmic bytes (SURVEY.md 8d) / launch time measured by HIP events on the "
+                          f"launch stream in {k['launches']} instrumented launches right after the timed region; the fp32 feature "
+                          f"set is {feat_mb:.1f} MB and " + ("fits the 256 MiB Infinity Cache, so `achieved` is an on-die rate and can "
+                          "exceed the HBM peak: hbm_side_* = PMC bytes beyond L2 (2*FETCH_SIZE + WRITE_SIZE) / the same time"
+                          if in_cache else "does not fit the 256 MiB Infinity Cache"))
             if "valid_triples" in k:
                 r["valid_triples"] = k["valid_triples"]
             return r
 
-        roof = roofline(ksum["daf"], "3D deformable aggregation; algorithmic bytes per SURVEY.md 8(d); the 92 MB fp32 "
-                        "feature set fits the 256 MiB Infinity Cache, so rows can be served on-die") if "daf" in ksum else None
+        roof = roofline(ksum["daf"], "3D deformable aggregation (daf_fwd_rows)") if "daf" in ksum else None
         roof2 = roofline(ksum["msda"], "camera-grouped MSDeformAttn sampling over the value_proj output") if "msda" in ksum else None
         line = {
             "metric": "frames/sec (6-cam sample) + MSDeformAttn HBM GB/s, R50 704x256 @1/2/4/8 GPU",
@@ -323,7 +338,8 @@ def main():
             "config": {"workload": f"simpb_nus_r{args.depth}_img_{args.image_wh[0]}x{args.image_wh[1]}: 6-cam frames, "
                                    f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, {args.streams} stream(s) x bs={args.bs} per GPU, temporal",
                        "streams_per_gpu": args.bs * args.streams, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "head_dtype": "f32 throughout; value_proj on the FP16 matrix cores with split operands and f32 accumulators (fp32-grade: same 2e-5 bound vs float64 as the exact kernel)", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
-                       if world > 1 else "single GPU", "num_query2d_last_frame": n2, "frame_runner": mode},
+                       if world > 1 else "single GPU", "inputs": "pinned host frames, H2D inside the timed step" if args.h2d else "resident in HBM",
+                       "fp16_matrix_step": "2 x v_mfma_f32_32x32x8f16 (csrc/mfma_f16.h)", "num_query2d_last_frame": n2, "frame_runner": mode},
             "roofline": roof, "roofline_msda": roof2,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -245,7 +245,9 @@ typedef struct simpb_mlp_chain {
 } simpb_mlp_chain;
 typedef struct simpb_mlp_args {
   int num_rows, num_chains;
-  int weights_transposed;  /* 1: LINEAR.w is [in_dim, out_dim] (VALU kernel); 0: nn.Linear's [out_dim, in_dim] (MFMA kernel) */
+  int weights_transposed;  /* 0: LINEAR.w is nn.Linear's [out_dim, in_dim] (16-row MFMA kernel); 1: [in_dim, out_dim] (VALU
+                            * kernel); 2: k4-packed [in_dim / 4][out_dim][4] for layers with in_dim % 4 == 0, nn.Linear's
+                            * layout for the others (4-row kernel on the 4x4 matrix blocks: 225 workgroups for 900 rows) */
   int reserved;
   simpb_mlp_chain chain[SIMPB_MLP_MAX_CHAINS];
 } simpb_mlp_args;

@@ -475,6 +475,169 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
   SIMPB_STAMP(127);
 }
 
+
+// ---- 4-row variant on the 4x4 matrix blocks (weights_transposed == 2).
+// Why: a chain over M = 900 rows in 16-row workgroups is 57 workgroups on 256 CUs (round-1 profile: MFMA busy 0.066, 64 %
+// of wave cycles waiting), and a 16x16 tile cannot be made shorter without wasting it. v_mfma_f32_4x4x1f32 multiplies
+// SIXTEEN independent 4x4 blocks per instruction at the same flop rate: block b = output columns 4b..4b+3 of a wave's 64
+// columns, the four rows of the block = the four rows of the workgroup, k advances by one per instruction. So 4 rows per
+// workgroup lose nothing: 225 workgroups for 900 rows, each with a quarter of the matrix work per layer.
+//   lane l = 4*b + j: A operand = x[row j][k] (LDS), B operand = W[column 64*wave + l][k], D[i] = out[row i][column].
+// Weights come k4-packed, Wp[k / 4][column][k % 4] (host repack, plugin/fused.py): the B operands of four k for a
+// lane are one 16-byte load, and a wave-load is 1 KiB contiguous. No weight staging through LDS, no barrier inside a layer.
+constexpr int kR4 = 4;
+
+__device__ __forceinline__ float wave_sum(float x) { x = half_wave_sum(x); return x + __shfl_xor(x, 32); }
+
+__global__ __launch_bounds__(256) void mlp_chain_r4_kernel(simpb_mlp_args args) {
+  constexpr int kThreads = 256;
+  __shared__ float act[2][kR4][kMaxDim + 4];
+  const simpb_mlp_chain& ch = args.chain[blockIdx.y];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * kR4;
+  const int N = args.num_rows;
+
+  if (ch.in_mode == SIMPB_MLP_IN_SINE2D) {
+    for (int idx = tid; idx < kR4 * 256; idx += kThreads) {
+      const int r = idx >> 8, j = idx & 255;
+      const int row = row0 + r;
+      float v = 0.f;
+      if (row < N) {
+        const int axis = j < 128 ? 1 : 0, i = j & 127;
+        const float coord = ch.x[(size_t)row * ch.ldx + axis] * 6.283185307179586f;
+        const float dim_t = powf(10000.f, (float)(2 * (i >> 1)) / 128.f);
+        const float p = coord / dim_t;
+        v = (i & 1) ? cosf(p) : sinf(p);
+      }
+      act[0][r][j] = v;
+    }
+  } else {
+    for (int idx = tid; idx < kR4 * ch.in_dim; idx += kThreads) {
+      const int r = idx / ch.in_dim, k = idx - r * ch.in_dim;
+      const int row = row0 + r;
+      float v = 0.f;
+      if (row < N) {
+        v = ch.x[(size_t)row * ch.ldx + k];
+        if (ch.x2) v += ch.x2[(size_t)row * ch.ldx2 + k];
+      }
+      act[0][r][k] = v;
+    }
+  }
+  __syncthreads();
+
+  int cur = 0;
+  int width = ch.in_mode == SIMPB_MLP_IN_SINE2D ? 256 : ch.in_dim;
+  for (int o = 0; o < ch.n_ops; ++o) {
+    const simpb_mlp_op& op = ch.ops[o];
+    if (op.type == SIMPB_MLP_LINEAR) {
+      const int K = op.in_dim, D = op.out_dim;
+      if ((K & 3) == 0) {  // k4-packed weights
+        if (wave * 64 < D) {
+          const int n = tid;
+          const bool cv = n < D;
+          const float4* wp = reinterpret_cast<const float4*>(op.w) + (cv ? n : 0);
+          const float* ar = &act[cur][lane & 3][0];
+          const float bias = (op.b && cv) ? op.b[n] : 0.f;
+          const int steps = K >> 2;                 // one step = 4 k = one 16-byte B load + one 16-byte A read
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          constexpr int G = 8;                      // steps per register set; two sets in flight
+          float4 wa[G], wb[G];
+          auto fetch = [&](float4* dst, int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) dst[j] = wp[(size_t)min(g * G + j, steps - 1) * D];  // unconditional, clamped
+          };
+          auto work = [&](const float4* w, int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+              const int st = g * G + j;
+              if (st < steps) {  // wave-uniform
+                const float4 a = *reinterpret_cast<const float4*>(ar + 4 * st);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, w[j].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, w[j].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, w[j].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, w[j].w, acc1, 0, 0, 0);
+              }
+            }
+          };
+          const int groups = (steps + G - 1) / G;
+          fetch(wa, 0);
+          for (int g = 0; g < groups; g += 2) {
+            fetch(wb, g + 1);
+            work(wa, g);
+            fetch(wa, g + 2);
+            if (g + 1 < groups) work(wb, g + 1);
+          }
+          if (cv) {
+#pragma unroll
+            for (int i = 0; i < kR4; ++i) {
+              const float v = acc0[i] + acc1[i] + bias;
+              act[cur ^ 1][i][n] = op.relu ? fmaxf(v, 0.f) : v;
+            }
+          }
+        }
+      } else if (tid < D) {  // K = 2, 3, ...: weights as stored, [D][K]
+        float acc[kR4];
+        const float b = op.b ? op.b[tid] : 0.f;
+#pragma unroll
+        for (int r = 0; r < kR4; ++r) acc[r] = b;
+        const float* wr = op.w + (size_t)tid * K;
+        for (int k = 0; k < K; ++k) {
+          const float wv = wr[k];
+#pragma unroll
+          for (int r = 0; r < kR4; ++r) acc[r] = fmaf(act[cur][r][k], wv, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < kR4; ++r) act[cur ^ 1][r][tid] = op.relu ? fmaxf(acc[r], 0.f) : acc[r];
+      }
+      __syncthreads();
+      cur ^= 1;
+      width = D;
+    } else {
+      // LayerNorm: wave r = row r, 64 lanes x 4 elements
+      const int D = op.in_dim;
+      const int r = wave;
+      float g[kMaxDim / 64], be[kMaxDim / 64], v[kMaxDim / 64];
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < kMaxDim / 64; ++j) {
+        const int e = lane + 64 * j;
+        const bool in = e < D;
+        g[j] = in ? op.w[e] : 0.f;
+        be[j] = in ? op.b[e] : 0.f;
+        v[j] = in ? act[cur][r][e] : 0.f;
+        sum += v[j];
+      }
+      sum = wave_sum(sum);
+      const float mean = sum / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < kMaxDim / 64; ++j) {
+        const float d = (lane + 64 * j) < D ? v[j] - mean : 0.f;
+        q += d * d;
+      }
+      q = wave_sum(q);
+      const float inv = 1.f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+      for (int j = 0; j < kMaxDim / 64; ++j) {
+        const int e = lane + 64 * j;
+        if (e < D) act[cur][r][e] = (v[j] - mean) * inv * g[j] + be[j];
+      }
+      __syncthreads();
+    }
+  }
+  for (int idx = tid; idx < kR4 * width; idx += kThreads) {
+    const int r = idx / width, t = idx - r * width;
+    const int row = row0 + r;
+    if (row < N) {
+      float v = act[cur][r][t];
+      if (ch.out_scale) v *= ch.out_scale[t];
+      if (ch.post) v = post_stage(ch, v, row, t);
+      ch.out[(size_t)row * ch.ldo + t] = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream) {
@@ -503,7 +666,11 @@ extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream)
     }
   }
   (void)hipGetLastError();
-  if (args->weights_transposed) {
+  if (args->weights_transposed == 2) {
+    // 4-row matrix-core variant (k4-packed weights): 4 rows x 4 waves
+    dim3 grid((args->num_rows + kR4 - 1) / kR4, args->num_chains);
+    hipLaunchKernelGGL(mlp_chain_r4_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), *args);
+  } else if (args->weights_transposed) {
     // VALU variant (weights [in][out]): 4 rows x 8 waves, split-K with 16-byte weight loads
     constexpr int R = 4, WAVES = 8;
     dim3 grid((args->num_rows + R - 1) / R, args->num_chains);

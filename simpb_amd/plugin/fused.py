@@ -14,6 +14,9 @@ from .ops import _stream
 MAX_OPS, MAX_CHAINS = 12, 8
 POST_NONE, POST_REFINE3D, POST_REFINE2D, POST_SIGMOID = 0, 1, 2, 3
 TRANSPOSED_WEIGHTS = False  # False: matrix-core kernel on the weights as stored; True: VALU kernel on transposed copies
+# True (shipped): 4-row workgroups on the 4x4 matrix blocks, weights k4-packed [in/4][out][4] (csrc/mlp_chain.hip:
+# mlp_chain_r4_kernel): 225 workgroups for 900 rows instead of 57. Takes precedence over TRANSPOSED_WEIGHTS.
+ROWS4 = True
 LINEAR, LAYERNORM = 0, 1
 IN_ROWS, IN_SINE2D = 0, 1
 
@@ -78,13 +81,29 @@ class ChainPlan:
             self._wt[key] = hit
         return hit[1]
 
+    def _packed(self, lin):
+        """Wp[k // 4][n][k % 4] = W[n][k] (f32, contiguous), refreshed when the parameter is replaced or modified."""
+        key = ("k4", id(lin))
+        w = lin.weight
+        tag = (w.data_ptr(), w._version, w.device)
+        hit = self._wt.get(key)
+        if hit is None or hit[0] != tag:
+            n, k = w.shape
+            hit = (tag, w.detach().float().t().reshape(k // 4, 4, n).permute(0, 2, 1).contiguous())
+            self._wt[key] = hit
+        return hit[1]
+
     def fill(self, chain, keep):
         chain.n_ops = len(self.ops)
         for j, (typ, din, dout, relu, m) in enumerate(self.ops):
             op = chain.ops[j]
             op.type, op.in_dim, op.out_dim, op.relu = typ, din, dout, relu
             if typ == LINEAR:
-                if TRANSPOSED_WEIGHTS:
+                if ROWS4 and din % 4 == 0:
+                    wp = self._packed(m)
+                    keep.append(wp)
+                    op.w = wp.data_ptr()
+                elif TRANSPOSED_WEIGHTS and not ROWS4:
                     wt = self._transposed(m)
                     keep.append(wt)
                     op.w = wt.data_ptr()
@@ -129,7 +148,7 @@ def run_chains(jobs, num_rows, device):
         raise ValueError("1..8 chains per launch")
     args = _Args()
     args.num_rows, args.num_chains = int(num_rows), len(jobs)
-    args.weights_transposed = 1 if TRANSPOSED_WEIGHTS else 0
+    args.weights_transposed = 2 if ROWS4 else (1 if TRANSPOSED_WEIGHTS else 0)
     keep = []
     for c, job in enumerate(jobs):
         ch = args.chain[c]
