@@ -331,20 +331,30 @@ def test_fused_backbone_epilogue_matches_plain_fp16_backbone():
     assert float((got - want).abs().mean()) <= 2e-3 * scale
 
 
-def test_mlp_chain_valu_variant_matches_mfma_variant():
-    """The two kernels behind simpb_mlp_chain_forward (matrix-core on weights as stored; VALU on
-    transposed weights) agree."""
+def test_mlp_chain_kernel_variants_agree():
+    """The three kernels behind simpb_mlp_chain_forward agree: 4-row workgroups on the 4x4 matrix blocks with k4-packed
+    weights (shipped), 16-row workgroups on 16x16 tiles with the weights as stored, VALU on transposed weights; on a row
+    count that is not a multiple of either tile, through a refinement chain (256-wide layers, LayerNorms, 11-wide head)
+    and through the 3D anchor encoder (3- and 2-wide first layers, 128/32/32/64-wide branches)."""
     from simpb_amd.plugin import fused
-    from simpb_amd.plugin.detection3d import SparseBox3DRefinementModule
+    from simpb_amd.plugin.detection3d import SparseBox3DEncoder, SparseBox3DRefinementModule
     ref3 = SparseBox3DRefinementModule(embed_dims=256, num_cls=10, refine_yaw=True, with_quality_estimation=True).cuda()
     synth.load_procedural(ref3, seed=7)
     x = torch.randn(1, 333, 256, device="cuda")
     e = torch.randn(1, 333, 256, device="cuda")
-    a = fused.chain_forward(ref3.layers, x, e)
-    old = fused.TRANSPOSED_WEIGHTS
+    enc = SparseBox3DEncoder(embed_dims=[128, 32, 32, 64], vel_dims=3, mode="cat", output_fc=False, in_loops=1, out_loops=4).cuda()
+    synth.load_procedural(enc, seed=9)
+    anchor = torch.randn(1, 333, 11, device="cuda")
+    old = fused.ROWS4, fused.TRANSPOSED_WEIGHTS
+    outs = {}
     try:
-        fused.TRANSPOSED_WEIGHTS = True
-        b = fused.chain_forward(ref3.layers, x, e)
+        for name, (r4, tr) in dict(rows4=(True, False), rows16=(False, False), valu=(False, True)).items():
+            fused.ROWS4, fused.TRANSPOSED_WEIGHTS = r4, tr
+            with torch.no_grad():
+                outs[name] = (fused.chain_forward(ref3.layers, x, e), enc(anchor))
     finally:
-        fused.TRANSPOSED_WEIGHTS = old
-    assert float((a - b).abs().max()) < 2e-5
+        fused.ROWS4, fused.TRANSPOSED_WEIGHTS = old
+    for name in ("rows16", "valu"):
+        for got, want in zip(outs["rows4"], outs[name]):
+            assert got.shape == want.shape
+            assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), name
