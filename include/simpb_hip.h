@@ -165,10 +165,13 @@ int simpb_layernorm_f32(float* out, int ldo, const float* x0, int ld0, int k0, c
  * [num_images = bs*cams, H_l, W_l, channels] in memory (what a channels_last backbone emits), f16
  * (src_is_half) or f32; level_ptrs/level_hw are HOST arrays of num_levels device pointers / H_l*W_l.
  * col_feats f32 [bs, cams * sum_l H_l*W_l, channels], camera-major then level then row-major, as
- * ops/src/deformable_aggregation.cpp:22-28 expects. channels % 8 == 0. */
+ * ops/src/deformable_aggregation.cpp:22-28 expects. channels % 8 == 0. level_bias (HOST array of num_levels device
+ * pointers, or NULL; entries may be NULL): per-channel bias of the same dtype added on the way (the last FPN
+ * convolution then runs without its bias: mmdet FPN.fpn_convs, config :90-99); f16 sums are rounded to f16 first,
+ * so the tokens are the numbers the separate bias pass produced. */
 #define SIMPB_MAX_LEVELS 8
-int simpb_format_tokens(float* col_feats, const void* const* level_ptrs, const int* level_hw, int num_levels,
-                        int num_images, int channels, int src_is_half, void* stream);
+int simpb_format_tokens(float* col_feats, const void* const* level_ptrs, const void* const* level_bias,
+                        const int* level_hw, int num_levels, int num_images, int channels, int src_is_half, void* stream);
 
 /* Backbone convolution epilogue after conv-BN folding (tools/fuse_conv_bn.py:10-48): in place,
  * y f16 [num_pixels, channels] (NHWC) = relu?(y + bias[c] + residual?). bias f16 [channels]; residual f16
@@ -179,13 +182,15 @@ int simpb_bias_act_nhwc_f16(void* y, const void* bias, const void* residual, lon
 /* A whole BN-folded 1x1 convolution of the fp16 channels_last backbone in one launch:
  *   y[n, ho, wo, :] = relu?( x[n, ho*stride, wo*stride, :] . weight^T + bias (+ residual[n, ho, wo, :]) )
  * x f16 [num_images, in_h, in_w, in_channels] (NHWC), weight f16 [out_channels, in_channels], bias f16 [out_channels],
- * residual f16 like y or NULL, y f16 [num_images, ho, wo, out_channels] with ho = (in_h - 1) / stride + 1; fp32
+ * residual f16 like y or NULL (with residual_upsample2x: f16 [num_images, ho / 2, wo / 2, out_channels], read with
+ * nearest-neighbour 2x upsampling = the FPN top-down sum lateral[i-1] += interpolate(lateral[i]) of mmdet FPN.forward;
+ * ho, wo even), y f16 [num_images, ho, wo, out_channels] with ho = (in_h - 1) / stride + 1; fp32
  * accumulate. stride 1 or 2; in_channels % 64 == 0, out_channels % 8 == 0; 16-byte aligned. These are conv1 / conv3 /
  * downsample of every ResNet bottleneck and the FPN lateral convolutions (mmdet ResNet + FPN of
  * projects/configs/simpb_nus_r50_img_704x256.py:79-99 after tools/fuse_conv_bn.py:10-48). */
 int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const void* bias, const void* residual,
                            int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride, int relu,
-                           void* stream);
+                           int residual_upsample2x, void* stream);
 
 /* Attention core of torch.nn.MultiheadAttention (between in_proj and out_proj), exact fp32, flash
  * style, head_dim = 64: out[b,q,h*64+d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d].

@@ -31,10 +31,19 @@ constexpr int LDH = BK + 8;   // halfs per staged row (144 B): conflict-free 16-
 constexpr int LDC = BN + 1;   // floats per row of the epilogue tile
 constexpr int kThreads = 256;
 
+// pixel index of output pixel p = (n, ho, wo) in a residual map of HALF the size, read with nearest-neighbour 2x
+// upsampling (F.interpolate(mode="nearest") of an exact 2x: source = floor(dst / 2)): the FPN top-down path
+__device__ __forceinline__ int up2(int p, int Ho, int Wo) {
+  const int n = p / (Ho * Wo), rem = p - n * (Ho * Wo);
+  const int ho = rem / Wo, wo = rem - ho * Wo;
+  return (n * (Ho >> 1) + (ho >> 1)) * (Wo >> 1) + (wo >> 1);
+}
+
 __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restrict__ y, const _Float16* __restrict__ x,
                                                                const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                                                                const _Float16* __restrict__ residual, int P_out, int Cin,
-                                                               int Cout, int relu, int stride, int Ho, int Wo, int H, int W) {
+                                                               int Cout, int relu, int stride, int Ho, int Wo, int H, int W,
+                                                               int res_up) {
   // the epilogue tile reuses the staging memory (33 KB per workgroup instead of 61: four workgroups per CU)
   constexpr int kStageBytes = (BM + BN) * LDH * 2, kTileBytes = BM * LDC * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[kStageBytes > kTileBytes ? kStageBytes : kTileBytes];
@@ -107,7 +116,8 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * kThreads;
-      const int p = min(p0 + (idx >> 3), P_out - 1);
+      int p = min(p0 + (idx >> 3), P_out - 1);
+      if (res_up) p = up2(p, Ho, Wo);
       rres[i] = *reinterpret_cast<const h16x8*>(residual + (size_t)p * Cout + c0 + (idx & 7) * 8);
     }
   }
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
         const int c = c0 + c8 + e;
         if (c < Cout) {
           float t = v[e] + (float)bias[c];
-          if (residual) t += (float)residual[(size_t)p * Cout + c];
+          if (residual) t += (float)residual[(size_t)(res_up ? up2(p, Ho, Wo) : p) * Cout + c];
           y[(size_t)p * Cout + c] = (_Float16)(relu ? fmaxf(t, 0.f) : t);
         }
       }
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
 
 extern "C" int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const void* bias, const void* residual,
                                       int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride,
-                                      int relu, void* stream) {
+                                      int relu, int residual_upsample2x, void* stream) {
   if (!y || !x || !weight || !bias || num_images <= 0 || in_h <= 0 || in_w <= 0 || in_channels <= 0 || out_channels <= 0 ||
       (stride != 1 && stride != 2) || in_channels % BK != 0 || out_channels % 8 != 0)  // BK = 64
     return SIMPB_EINVAL;
@@ -185,6 +195,7 @@ extern "C" int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight
        reinterpret_cast<size_t>(bias) | reinterpret_cast<size_t>(residual)) & 15)
     return SIMPB_EINVAL;
   const int ho = (in_h - 1) / stride + 1, wo = (in_w - 1) / stride + 1;
+  if (residual_upsample2x && (!residual || (ho & 1) || (wo & 1))) return SIMPB_EINVAL;
   const long long p_out = (long long)num_images * ho * wo;
   if (p_out > (1ll << 30)) return SIMPB_EINVAL;
   (void)hipGetLastError();
@@ -193,6 +204,6 @@ extern "C" int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight
   hipLaunchKernelGGL(conv1x1_f16_kernel, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                      static_cast<_Float16*>(y), static_cast<const _Float16*>(x), static_cast<const _Float16*>(weight),
                      static_cast<const _Float16*>(bias), static_cast<const _Float16*>(residual), (int)p_out, in_channels,
-                     out_channels, relu, stride, ho, wo, in_h, in_w);
+                     out_channels, relu, stride, ho, wo, in_h, in_w, residual_upsample2x ? 1 : 0);
   return simpb_check_launch();
 }

@@ -17,6 +17,7 @@ namespace {
 
 struct LevelArgs {
   const void* src[SIMPB_MAX_LEVELS];
+  const void* bias[SIMPB_MAX_LEVELS];  // per-channel bias of the convolution that produced the level (same dtype), or null
   int hw[SIMPB_MAX_LEVELS];       // H*W of each level
   int start[SIMPB_MAX_LEVELS];    // token offset of each level inside one camera's block
 };
@@ -29,6 +30,7 @@ __global__ void format_tokens_kernel(float* __restrict__ col, LevelArgs lv, int 
   const int c8 = C / 8;
   const long long n = (long long)images * hw * c8;
   const T* __restrict__ src = static_cast<const T*>(lv.src[lvl]);
+  const T* __restrict__ bias = static_cast<const T*>(lv.bias[lvl]);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % c8) * 8;
     const long long tok = i / c8;            // image * hw + pixel
@@ -47,6 +49,22 @@ __global__ void format_tokens_kernel(float* __restrict__ col, LevelArgs lv, int 
       const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
+    if (bias) {  // the last FPN convolution's bias rides along (it ran without one): fp32 add, like the unfused
+                 // fp16 add + fp16->fp32 cast up to one fp16 rounding less
+      if constexpr (sizeof(T) == 2) {
+        const uint4 braw = *reinterpret_cast<const uint4*>(bias + c);
+        const __half2* b2 = reinterpret_cast<const __half2*>(&braw);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float2 f = __half22float2(b2[j]);
+          v[2 * j] = __half2float(__float2half_rn(v[2 * j] + f.x));      // round to fp16 as the convolution's own
+          v[2 * j + 1] = __half2float(__float2half_rn(v[2 * j + 1] + f.y));  // bias epilogue did: same numbers
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bias[c + j];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) simpb::pin(v[j]);
     simpb::loads_retired();  // store_fence.h (grid-stride loop: the next row's load must not be in flight at the store)
@@ -58,8 +76,9 @@ __global__ void format_tokens_kernel(float* __restrict__ col, LevelArgs lv, int 
 
 }  // namespace
 
-extern "C" int simpb_format_tokens(float* col_feats, const void* const* level_ptrs, const int* level_hw, int num_levels,
-                                   int num_images, int channels, int src_is_half, void* stream) {
+extern "C" int simpb_format_tokens(float* col_feats, const void* const* level_ptrs, const void* const* level_bias,
+                                   const int* level_hw, int num_levels, int num_images, int channels, int src_is_half,
+                                   void* stream) {
   if (!col_feats || !level_ptrs || !level_hw || num_levels <= 0 || num_levels > SIMPB_MAX_LEVELS || num_images <= 0 ||
       channels <= 0 || channels % 8 != 0)
     return SIMPB_EINVAL;
@@ -68,6 +87,7 @@ extern "C" int simpb_format_tokens(float* col_feats, const void* const* level_pt
   for (int l = 0; l < num_levels; ++l) {
     if (!level_ptrs[l] || level_hw[l] <= 0) return SIMPB_EINVAL;
     lv.src[l] = level_ptrs[l];
+    lv.bias[l] = level_bias ? level_bias[l] : nullptr;
     lv.hw[l] = level_hw[l];
     lv.start[l] = total;
     total += level_hw[l];

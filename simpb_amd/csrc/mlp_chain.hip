@@ -561,12 +561,18 @@ __global__ __launch_bounds__(256) void mlp_chain_r4_kernel(simpb_mlp_args args) 
             }
           };
           const int groups = (steps + G - 1) / G;
-          fetch(wa, 0);
+#ifdef SIMPB_CHAIN_ROTATE
+          const int rot = blockIdx.x % groups;
+#else
+          const int rot = 0;
+#endif
+          auto grp = [&](int gi) __attribute__((always_inline)) { const int t = gi + rot; return t >= groups ? t - groups : t; };
+          fetch(wa, grp(0));
           for (int g = 0; g < groups; g += 2) {
-            fetch(wb, g + 1);
-            work(wa, g);
-            fetch(wa, g + 2);
-            if (g + 1 < groups) work(wb, g + 1);
+            fetch(wb, grp(g + 1 < groups ? g + 1 : g));
+            work(wa, grp(g));
+            fetch(wa, grp(g + 2 < groups ? g + 2 : g));
+            if (g + 1 < groups) work(wb, grp(g + 1));
           }
           if (cv) {
 #pragma unroll

@@ -162,11 +162,22 @@ class FPN(BaseModule):
             laterals = [None] * n
             for i in range(n - 1, -1, -1):
                 conv = self.lateral_convs[i].conv
-                up = None
+                xin = inputs[i + self.start_level]
+                up, up2x = None, False
                 if i < n - 1:
-                    up = F.interpolate(laterals[i + 1], size=inputs[i + self.start_level].shape[2:], **self.upsample_cfg)
-                laterals[i] = conv1x1_nhwc(inputs[i + self.start_level], conv.weight, conv.bias, up, relu=False)
+                    hh, ww = xin.shape[2:]
+                    if (hh % 2 == 0 and ww % 2 == 0 and tuple(laterals[i + 1].shape[2:]) == (hh // 2, ww // 2)
+                            and "scale_factor" not in self.upsample_cfg):
+                        up, up2x = laterals[i + 1], True  # nearest 2x read inside the launch: no upsampled map
+                    else:
+                        up = F.interpolate(laterals[i + 1], size=xin.shape[2:], **self.upsample_cfg)
+                laterals[i] = conv1x1_nhwc(xin, conv.weight, conv.bias, up, relu=False, residual_upsample2x=up2x)
+            self.deferred_output_bias = bool(getattr(self, "defer_output_bias", False))
+            if self.deferred_output_bias:
+                # the caller (SimPB.extract_feat) adds the biases while it writes the tokens (ops.format_tokens)
+                return tuple(F.conv2d(laterals[i], self.fpn_convs[i].conv.weight, None, padding=1) for i in range(n))
             return tuple(self.fpn_convs[i](laterals[i]) for i in range(n))
+        self.deferred_output_bias = False
         laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
         for i in range(len(laterals) - 1, 0, -1):
             laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
@@ -246,11 +257,20 @@ class SimPB(BaseModule):
         if self.fp16_enabled:
             img = img.half().contiguous(memory_format=torch.channels_last)
         feature_maps = self.img_backbone(img)
+        biases = None
         if self.img_neck is not None:
+            # fp16 fused path: the four output convolutions of the FPN run without their bias and the bias is added
+            # by the pass that writes the tokens (one launch for all levels instead of four bias launches + it)
+            defer = (self.fp16_enabled and img.is_cuda and isinstance(self.img_neck, FPN)
+                     and all(m.conv.bias is not None and m.conv.bias.dtype == torch.float16 and m.conv.padding == (1, 1)
+                             and m.conv.out_channels % 8 == 0 for m in self.img_neck.fpn_convs))
+            self.img_neck.defer_output_bias = defer
             feature_maps = list(self.img_neck(feature_maps))
+            if getattr(self.img_neck, "deferred_output_bias", False):  # (False when the neck took its unfused route)
+                biases = [m.conv.bias for m in self.img_neck.fpn_convs]
         if feature_maps[0].is_cuda and feature_maps[0].shape[1] % 8 == 0:
             # channels_last maps are already token-major in memory: one conversion pass into col_feats
-            return format_tokens(feature_maps, bs, num_cams)
+            return format_tokens(feature_maps, bs, num_cams, biases=biases)
         feature_maps = [f.float() if self.fp16_enabled else f for f in feature_maps]
         feature_maps = [torch.reshape(f, (bs, num_cams) + f.shape[1:]) for f in feature_maps]
         return feature_maps_format(feature_maps)

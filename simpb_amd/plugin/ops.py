@@ -285,10 +285,10 @@ def attention_f32(q, k, v, num_heads, query_cam=None, group_start=None):
     return out
 
 
-def format_tokens(levels, bs, num_cams):
+def format_tokens(levels, bs, num_cams, biases=None):
     """feature_maps_format for channels_last level tensors [bs*cams, C, H, W] (f16 or f32), one
     pass (csrc/format.hip). Returns [col_feats, spatial_shape, scale_start_index] like
-    feature_maps_format."""
+    feature_maps_format. biases: per-level [C] tensors (same dtype) added on the way, or None."""
     _require_gpu(*levels)
     c = levels[0].shape[1]
     dtype = levels[0].dtype
@@ -306,7 +306,12 @@ def format_tokens(levels, bs, num_cams):
     col = torch.empty(bs, num_cams * tokens, c, device=levels[0].device, dtype=torch.float32)
     ptrs = (ctypes.c_void_p * len(srcs))(*[f.data_ptr() for f in srcs])
     hws = (ctypes.c_int * len(srcs))(*[h * w for h, w in shapes])
-    status = _lib.lib().simpb_format_tokens(_ptr(col), ptrs, hws, len(srcs), bs * num_cams, c,
+    bptrs = None
+    if biases is not None:
+        if len(biases) != len(srcs) or any(b is not None and (b.dtype != dtype or b.numel() != c or not b.is_contiguous()) for b in biases):
+            raise ValueError("biases: one contiguous [C] tensor of the levels' dtype per level (or None)")
+        bptrs = (ctypes.c_void_p * len(srcs))(*[b.data_ptr() if b is not None else None for b in biases])
+    status = _lib.lib().simpb_format_tokens(_ptr(col), ptrs, bptrs, hws, len(srcs), bs * num_cams, c,
                                             1 if dtype == torch.float16 else 0, _stream())
     _lib.check(status, "simpb_format_tokens")
     spatial_shape, scale_start_index = _shape_tables(shapes, num_cams, col.device)
@@ -330,9 +335,10 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
-def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1):
+def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_upsample2x=False):
     """relu?(conv1x1(x, weight, stride) + bias + residual?) for a channels_last f16 tensor, one launch
-    (csrc/conv1x1.hip). x [N, Cin, H, W]; weight [Cout, Cin, 1, 1] f16; bias f16 [Cout]."""
+    (csrc/conv1x1.hip). x [N, Cin, H, W]; weight [Cout, Cin, 1, 1] f16; bias f16 [Cout]. With residual_upsample2x the
+    residual is [N, Cout, H/2, W/2] and is read with nearest-neighbour 2x upsampling (the FPN top-down sum)."""
     _require_gpu(x, weight, bias)
     n, cin, h, w = x.shape
     cout = weight.shape[0]
@@ -341,14 +347,18 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1):
         raise ValueError("conv1x1_nhwc takes channels_last f16 input, f16 [Cout, Cin, 1, 1] weight, Cin % 64 == 0, Cout % 8 == 0")
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     y = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float16, memory_format=torch.channels_last)
-    if residual is not None and (residual.shape != y.shape or residual.dtype != torch.float16
+    want = y.shape if not residual_upsample2x else (n, cout, ho // 2, wo // 2)
+    if residual_upsample2x and (residual is None or ho % 2 or wo % 2):
+        raise ValueError("residual_upsample2x needs a residual and even output sizes")
+    if residual is not None and (tuple(residual.shape) != tuple(want) or residual.dtype != torch.float16
                                  or not residual.is_contiguous(memory_format=torch.channels_last)):
         raise ValueError("residual must match the output (channels_last f16)")
     w2 = weight.reshape(cout, cin)
     if not w2.is_contiguous():
         w2 = w2.contiguous()
     status = _lib.lib().simpb_conv1x1_nhwc_f16(_ptr(y), _ptr(x), _ptr(w2), _ptr(bias), _ptr(residual) if residual is not None else None,
-                                               n, h, w, cin, cout, stride, 1 if relu else 0, _stream())
+                                               n, h, w, cin, cout, stride, 1 if relu else 0,
+                                               1 if residual_upsample2x else 0, _stream())
     _lib.check(status, "simpb_conv1x1_nhwc_f16")
     return y
 

@@ -481,3 +481,70 @@ def test_conv1x1_kernel_vs_conv2d(cin, cout, h, w, stride, res, relu):
     assert got.shape == want.shape and got.dtype == torch.float16 and got.is_contiguous(memory_format=torch.channels_last)
     err = (got.float() - want).abs()
     assert float((err - 1e-3 * want.abs()).max()) <= 2e-3   # fp16 output rounding: 2^-11 relative + small absolute
+
+
+@gpu
+@pytest.mark.parametrize("cin,cout,h,w", [(512, 256, 32, 88), (256, 256, 64, 176), (1024, 256, 16, 44), (192, 40, 6, 10)])
+def test_conv1x1_with_upsampled_residual(cin, cout, h, w):
+    """The FPN top-down sum lateral[i-1] = conv1x1(c[i-1]) + interpolate(lateral[i], nearest) (mmdet FPN.forward) with
+    the 2x nearest read done inside the launch, against the materialised F.interpolate + conv1x1 residual route (same
+    kernel, same arithmetic: bit-exact) and against fp32 F.conv2d."""
+    from simpb_amd.plugin.ops import conv1x1_nhwc
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(3, cin, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).half().cuda()
+    b = torch.randn(cout, generator=g).half().cuda()
+    coarse = torch.randn(3, cout, h // 2, w // 2, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    up = F.interpolate(coarse, size=(h, w), mode="nearest").contiguous(memory_format=torch.channels_last)
+    want = conv1x1_nhwc(x, wt, b, up, relu=False)
+    got = conv1x1_nhwc(x, wt, b, coarse, relu=False, residual_upsample2x=True)
+    assert torch.equal(got, want)
+    ref = F.conv2d(x.float(), wt.float(), b.float()) + up.float()
+    assert float((got.float() - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(ValueError):
+        conv1x1_nhwc(x, wt, b, up, relu=False, residual_upsample2x=True)   # residual must be the half-size map
+
+
+@gpu
+def test_format_tokens_with_level_bias_equals_bias_then_format():
+    """The FPN's output convolutions run without their bias and ops.format_tokens adds it while it writes the tokens:
+    same numbers as conv + fp16 bias add + format (the sum is rounded to fp16 first), for fp16 and fp32 levels; and the
+    whole fused neck equals the unfused neck on the same fp16 backbone features."""
+    from simpb_amd.plugin import ops
+    shapes = [(8, 22), (4, 11), (2, 6), (1, 3)]
+    for dtype in (torch.float16, torch.float32):
+        maps = [torch.from_numpy(synth.randn(f"fmtb.l{l}", (12, 16, h, w))).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+                for l, (h, w) in enumerate(shapes)]
+        bias = [torch.from_numpy(synth.randn(f"fmtb.b{l}", (16,))).to(dtype).cuda() for l in range(4)]
+        want = ops.format_tokens([(m + b.view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last) for m, b in zip(maps, bias)], 2, 6)
+        got = ops.format_tokens(maps, 2, 6, biases=bias)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+        part = ops.format_tokens(maps, 2, 6, biases=[bias[0], None, None, bias[3]])[0]
+        mixed = ops.format_tokens([(maps[0] + bias[0].view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last), maps[1], maps[2],
+                                   (maps[3] + bias[3].view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last)], 2, 6)[0]
+        assert torch.equal(part, mixed)
+
+
+@gpu
+def test_fused_neck_equals_unfused_neck():
+    from simpb_amd import configs, plugin
+    from simpb_amd.plugin import detector
+    cfg = configs.simpb_plus(anchor=synth.anchors(900))
+    model = plugin.build_detector(cfg["model"]).eval()
+    synth.load_procedural(model)
+    model = model.cuda().fuse_conv_bn().half_backbone()
+    img = synth.images(1, 1, (352, 128)).cuda()
+    with torch.no_grad():
+        got = model.extract_feat(img)
+        assert model.img_neck.deferred_output_bias
+        old = detector.CONV1X1_KERNEL
+        try:
+            detector.CONV1X1_KERNEL = False   # mmdet's statement: lateral convs, F.interpolate, adds, biased 3x3 convs
+            want = model.extract_feat(img)
+        finally:
+            detector.CONV1X1_KERNEL = old
+        assert not model.img_neck.deferred_output_bias
+    scale = float(want[0].abs().max())
+    assert float((got[0] - want[0]).abs().max()) <= 2e-2 * scale      # fp16 networks, different rounding points
+    assert float((got[0] - want[0]).abs().mean()) <= 2e-3 * scale
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])

@@ -31,6 +31,10 @@ def timeit(fn, iters=30, reps=5):
 
 
 def main():
+    import os
+    if len(sys.argv) > 1:  # a variant library (experiments)
+        import simpb_amd._lib as L
+        L.LIB = os.path.abspath(sys.argv[1])
     torch.manual_seed(0)
     enc3 = SparseBox3DEncoder([128, 32, 32, 64], vel_dims=3, mode="cat", output_fc=False, in_loops=1, out_loops=4).cuda().eval()
     enc2 = SparseBox2DEncoder(256, with_sin_embed=True, in_loops=1, out_loops=2).cuda().eval()
@@ -48,7 +52,13 @@ def main():
         ("encoder 2D sine (1536)", lambda: enc2(a2)),
         ("refine2d reg+cls+alpha (1536)", lambda: r2(f2, a2, e2)),
     ]:
-        print(f"{name:52s} {timeit(fn):7.1f} us")
+        from simpb_amd.plugin import fused
+        row = []
+        for r4 in (True, False):
+            fused.ROWS4 = r4
+            row.append(timeit(fn))
+        fused.ROWS4 = True
+        print(f"{name:52s} rows4 {row[0]:7.1f} us   rows16 {row[1]:7.1f} us")
 
 
 if __name__ == "__main__":
