@@ -485,6 +485,12 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
 //   lane l = 4*b + j: A operand = x[row j][k] (LDS), B operand = W[column 64*wave + l][k], D[i] = out[row i][column].
 // Weights come k4-packed, Wp[k / 4][column][k % 4] (host repack, plugin/fused.py): the B operands of four k for a
 // lane are one 16-byte load, and a wave-load is 1 KiB contiguous. No weight staging through LDS, no barrier inside a layer.
+// Measured (tools/chain_stamps.py, tools/bench_chain.py): ~10.4k cycles per 256x256 layer against ~19k for the 16-row kernel
+// (refine3d chain 29.6 us vs 42.3 us, anchor encoder 14.1 vs 18.6, 2D encoder 20.1 vs 28.6). The layer time is the same for
+// ONE busy wave (a 256 -> 11 head) as for four and does not change with eight accumulators, a branch-free step, or a
+// rotated k order across workgroups: v_mfma_f32_4x4x1f32 issues once per ~38 cycles on gfx950, i.e. at a quarter of the
+// 16x16x4 flop rate, so 4 rows per CU cost as many matrix cycles as 16 do. What is gained is the 4x CU count, not
+// matrix efficiency; the floor left is the 256 KB of weights per layer through one CU's 64 B/clk load path (4k cycles).
 constexpr int kR4 = 4;
 
 __device__ __forceinline__ float wave_sum(float x) { x = half_wave_sum(x); return x + __shfl_xor(x, 32); }
@@ -561,18 +567,12 @@ __global__ __launch_bounds__(256) void mlp_chain_r4_kernel(simpb_mlp_args args) 
             }
           };
           const int groups = (steps + G - 1) / G;
-#ifdef SIMPB_CHAIN_ROTATE
-          const int rot = blockIdx.x % groups;
-#else
-          const int rot = 0;
-#endif
-          auto grp = [&](int gi) __attribute__((always_inline)) { const int t = gi + rot; return t >= groups ? t - groups : t; };
-          fetch(wa, grp(0));
+          fetch(wa, 0);
           for (int g = 0; g < groups; g += 2) {
-            fetch(wb, grp(g + 1 < groups ? g + 1 : g));
-            work(wa, grp(g));
-            fetch(wa, grp(g + 2 < groups ? g + 2 : g));
-            if (g + 1 < groups) work(wb, grp(g + 1));
+            fetch(wb, g + 1);
+            work(wa, g);
+            fetch(wa, g + 2);
+            if (g + 1 < groups) work(wb, g + 1);
           }
           if (cv) {
 #pragma unroll

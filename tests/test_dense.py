@@ -5,6 +5,8 @@ float64 matmuls; the fused attention / FFN blocks against the unfused module rou
 Tolerance for fp32 GEMMs: 2e-5 * max|ref| (both sides fp32-exact products, different summation order)."""
 import numpy as np
 import pytest
+
+from simpb_amd import synth
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
