@@ -8,7 +8,8 @@ import sys
 NAMES = {"gemm_f32_kernel<64": "gemm_f32_kernel<64,4,64>", "gemm_f32_kernel<32, 2": "gemm_f32_kernel<32,2,128>",
          "gemm_f32_kernel<32, 4": "gemm_f32_kernel<32,4,64>", "attention_f32_kernel<false": "attention_f32_kernel<false>",
          "attention_f32_kernel<true": "attention_f32_kernel<true>", "mlp_chain_mfma": "mlp_chain_mfma_kernel",
-         "linear_f32_mfma": "linear_f32_mfma (value_proj)"}
+         "mlp_chain_r4": "mlp_chain_r4_kernel", "linear_f32_mfma": "linear_f32_mfma", "linear_f16x3": "linear_f16x3 (value_proj)",
+         "conv1x1_f16": "conv1x1_f16"}
 per = collections.defaultdict(dict)
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
@@ -34,8 +35,9 @@ for k, v in agg.items():
     print(k, out[k])
 json.dump(dict(
     command="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE "
-            "-- python bench.py --steps 10 --warmup 3 --no-cpu-baseline", round=1,
+            "-- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline", round=2,
     definition="mfma_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs) per dispatch, averaged "
-               "(the guide's MfmaUtil); every kernel here is exact fp32 on v_mfma_f32_32x32x2 / 16x16x4 (peak 157.3 TFLOP/s). "
+               "(the guide's MfmaUtil): the share of SIMD cycles with a matrix instruction in flight, whatever its flop rate "
+               "(v_mfma_f32_4x4x1f32 of mlp_chain_r4 keeps the pipe busy at a quarter of the 16x16x4 flop rate). "
                "Counters serialise the two HIP streams of the pipelined frame, so durations are per-kernel, not in-frame.",
     kernels=out), open(sys.argv[2], "w"), indent=1)
