@@ -491,6 +491,9 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
 // rotated k order across workgroups: v_mfma_f32_4x4x1f32 issues once per ~38 cycles on gfx950, i.e. at a quarter of the
 // 16x16x4 flop rate, so 4 rows per CU cost as many matrix cycles as 16 do. What is gained is the 4x CU count, not
 // matrix efficiency; the floor left is the 256 KB of weights per layer through one CU's 64 B/clk load path (4k cycles).
+// Also measured and dropped: 16 waves per workgroup with K split four ways and every weight of a layer requested up front
+// (partials meeting in LDS): the single wide chain gains (refine3d 29.6 -> 24.2 us, ~7k cycles per layer) but launches of
+// several chains lose more (anchor encoder 14.1 -> 60.6 us, refine2d 50.5 -> 78 us: 1024-thread workgroups, two per CU).
 constexpr int kR4 = 4;
 
 __device__ __forceinline__ float wave_sum(float x) { x = half_wave_sum(x); return x + __shfl_xor(x, 32); }
