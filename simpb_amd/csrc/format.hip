@@ -36,38 +36,38 @@ __global__ void format_tokens_kernel(float* __restrict__ col, LevelArgs lv, int 
     const long long tok = i / c8;            // image * hw + pixel
     const int img = (int)(tok / hw), pix = (int)(tok - (long long)img * hw);
     const T* s = src + tok * C + c;
-    float v[8];
+    // every load of the row (and of the bias) first, then one full wait: the previous row's stores of this grid-stride
+    // loop are retired with it and no counted wait releases consumers while anything is in flight (store_fence.h)
+    float v[8], bv[8];
+    const T* bp = bias ? bias + c : src;   // a valid address either way; the values are only used when bias != null
     if constexpr (sizeof(T) == 2) {
       const uint4 raw = *reinterpret_cast<const uint4*>(s);
+      const uint4 braw = *reinterpret_cast<const uint4*>(bp);
+      simpb::loads_retired();
       const __half2* h2 = reinterpret_cast<const __half2*>(&raw);
+      const __half2* b2 = reinterpret_cast<const __half2*>(&braw);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float2 f = __half22float2(h2[j]);
+        const float2 f = __half22float2(h2[j]), g = __half22float2(b2[j]);
         v[2 * j] = f.x; v[2 * j + 1] = f.y;
+        bv[2 * j] = g.x; bv[2 * j + 1] = g.y;
       }
     } else {
       const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+      const float4 ba = *reinterpret_cast<const float4*>(bp), bb = *reinterpret_cast<const float4*>(bp + 4);
+      simpb::loads_retired();
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      bv[0] = ba.x; bv[1] = ba.y; bv[2] = ba.z; bv[3] = ba.w; bv[4] = bb.x; bv[5] = bb.y; bv[6] = bb.z; bv[7] = bb.w;
     }
-    if (bias) {  // the last FPN convolution's bias rides along (it ran without one): fp32 add, like the unfused
-                 // fp16 add + fp16->fp32 cast up to one fp16 rounding less
-      if constexpr (sizeof(T) == 2) {
-        const uint4 braw = *reinterpret_cast<const uint4*>(bias + c);
-        const __half2* b2 = reinterpret_cast<const __half2*>(&braw);
+    if (bias) {  // the last FPN convolution's bias rides along (it ran without one)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float2 f = __half22float2(b2[j]);
-          v[2 * j] = __half2float(__float2half_rn(v[2 * j] + f.x));      // round to fp16 as the convolution's own
-          v[2 * j + 1] = __half2float(__float2half_rn(v[2 * j + 1] + f.y));  // bias epilogue did: same numbers
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bias[c + j];
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (sizeof(T) == 2) v[j] = __half2float(__float2half_rn(v[j] + bv[j]));  // rounded to fp16 as the
+        else v[j] += bv[j];                                                              // separate bias pass did
       }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) simpb::pin(v[j]);
-    simpb::loads_retired();  // store_fence.h (grid-stride loop: the next row's load must not be in flight at the store)
     float* d = col + ((long long)img * tokens_per_cam + lv.start[lvl] + pix) * C + c;
     *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);

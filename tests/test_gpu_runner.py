@@ -237,7 +237,8 @@ class _ReplayModel(torch.nn.Module):
 
 def test_pipelined_equals_plain_runner_with_real_backbone():
     """Whole detector (ResNet50+FPN with folded BN + decoder), 12 frames, through the graph runner and the
-    pipelined runner (two streams, four graphs, backbone(t+1) beside decoder(t)).
+    pipelined runner (two streams, four graphs, backbone(t+1) beside decoder(t)), the latter also with the frames
+    arriving in pinned host memory.
 
     The vendor's convolutions are not bit-reproducible from one run to the next (tools/pipe_determinism.py:
     the feature maps of two EAGER runs already differ in every frame), and a 1e-7 difference that flips one
@@ -262,14 +263,18 @@ def test_pipelined_equals_plain_runner_with_real_backbone():
     def snapshot(fm):
         return [t.clone() for t in list(fm)[:3]]
 
-    for name in ("graph", "pipe"):
+    for name in ("graph", "pipe", "pipe_h2d"):
         model = make()
         seen = []
-        if name == "pipe":
+        if name.startswith("pipe"):
             r = PipelinedRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=True)
+            # pipe_h2d: frames handed over in pinned host memory, copied inside the step on the backbone stream
+            # beside the previous frame's decoder (bench.py --h2d)
+            src = imgs if name == "pipe" else [x.cpu().pin_memory() for x in imgs]
             out = []
             for f in range(frames):
-                out.append(r.step(imgs[f], metas[f]))
+                out.append(r.step(src[f], metas[f]))
+                assert torch.equal(r.imgs[f % 2].cpu(), imgs[f].cpu()), (name, f)  # the frame the backbone just read
                 if f >= 1:  # the maps decoder(f-1) just read; backbone(f) wrote the other slot meanwhile
                     seen.append(snapshot(r.fm[(f - 1) % 2]))
             seen.append(snapshot(r.fm[(frames - 1) % 2]))
