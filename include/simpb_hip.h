@@ -184,13 +184,15 @@ int simpb_bias_act_nhwc_f16(void* y, const void* bias, const void* residual, lon
  * x f16 [num_images, in_h, in_w, in_channels] (NHWC), weight f16 [out_channels, in_channels], bias f16 [out_channels],
  * residual f16 like y or NULL (with residual_upsample2x: f16 [num_images, ho / 2, wo / 2, out_channels], read with
  * nearest-neighbour 2x upsampling = the FPN top-down sum lateral[i-1] += interpolate(lateral[i]) of mmdet FPN.forward;
- * ho, wo even), y f16 [num_images, ho, wo, out_channels] with ho = (in_h - 1) / stride + 1; fp32
+ * ho, wo even), y f16 [num_images, ho, wo, out_channels] with ho = (in_h - 1) / stride + 1; input_bias f16
+ * [in_channels] or NULL: x is first replaced by relu(x + input_bias) (rounded to f16), i.e. the epilogue of the
+ * BN-folded 3x3 convolution that produced x (bottleneck conv2 -> conv3) without a pass of its own; fp32
  * accumulate. stride 1 or 2; in_channels % 64 == 0, out_channels % 8 == 0; 16-byte aligned. These are conv1 / conv3 /
  * downsample of every ResNet bottleneck and the FPN lateral convolutions (mmdet ResNet + FPN of
  * projects/configs/simpb_nus_r50_img_704x256.py:79-99 after tools/fuse_conv_bn.py:10-48). */
 int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const void* bias, const void* residual,
                            int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride, int relu,
-                           int residual_upsample2x, void* stream);
+                           int residual_upsample2x, const void* input_bias, void* stream);
 
 /* Attention core of torch.nn.MultiheadAttention (between in_proj and out_proj), exact fp32, flash
  * style, head_dim = 64: out[b,q,h*64+d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d].

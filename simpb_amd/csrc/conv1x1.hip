@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
                                                                const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                                                                const _Float16* __restrict__ residual, int P_out, int Cin,
                                                                int Cout, int relu, int stride, int Ho, int Wo, int H, int W,
-                                                               int res_up) {
+                                                               int res_up, const _Float16* __restrict__ in_bias) {
   // the epilogue tile reuses the staging memory (33 KB per workgroup instead of 61: four workgroups per CU)
   constexpr int kStageBytes = (BM + BN) * LDH * 2, kTileBytes = BM * LDC * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[kStageBytes > kTileBytes ? kStageBytes : kTileBytes];
@@ -73,10 +73,14 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
 #pragma unroll
   for (int i = 0; i < NB; ++i) brow[i] = (size_t)min(c0 + sr + RS * i, Cout - 1) * Cin + sc;
   const int nchunks = Cin / BK;
-  h16x8 pa[2][NA], pb[2][NB];
+  h16x8 pa[2][NA], pb[2][NB], pin[2];
+  // in_bias: the INPUT is the raw output of the 3x3 convolution in front (ResNet bottleneck conv2 after BN folding); its
+  // epilogue x <- relu(x + in_bias[channel]) is applied while the tile is staged (fp32 add, one rounding to fp16: the
+  // numbers the separate bias_act pass wrote), so that pass and its trip through memory disappear
   auto fetch = [&](auto set_c, int chunk) __attribute__((always_inline)) {
     constexpr int set = decltype(set_c)::value;
     const int k0 = min(chunk, nchunks - 1) * BK;
+    if (in_bias) pin[set] = *reinterpret_cast<const h16x8*>(in_bias + k0 + sc);
 #pragma unroll
     for (int i = 0; i < NA; ++i) pa[set][i] = *reinterpret_cast<const h16x8*>(x + arow[i] + k0);
 #pragma unroll
@@ -85,7 +89,14 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
   auto stash = [&](auto set_c, int) __attribute__((always_inline)) {
     constexpr int set = decltype(set_c)::value;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<h16x8*>(&s_a[(sr + RS * i) * LDH + sc]) = pa[set][i];
+    for (int i = 0; i < NA; ++i) {
+      h16x8 v = pa[set][i];
+      if (in_bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)fmaxf((float)v[e] + (float)pin[set][e], 0.f);
+      }
+      *reinterpret_cast<h16x8*>(&s_a[(sr + RS * i) * LDH + sc]) = v;
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) *reinterpret_cast<h16x8*>(&s_b[(sr + RS * i) * LDH + sc]) = pb[set][i];
   };
@@ -187,12 +198,12 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
 
 extern "C" int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const void* bias, const void* residual,
                                       int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride,
-                                      int relu, int residual_upsample2x, void* stream) {
+                                      int relu, int residual_upsample2x, const void* input_bias, void* stream) {
   if (!y || !x || !weight || !bias || num_images <= 0 || in_h <= 0 || in_w <= 0 || in_channels <= 0 || out_channels <= 0 ||
       (stride != 1 && stride != 2) || in_channels % BK != 0 || out_channels % 8 != 0)  // BK = 64
     return SIMPB_EINVAL;
   if ((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(weight) |
-       reinterpret_cast<size_t>(bias) | reinterpret_cast<size_t>(residual)) & 15)
+       reinterpret_cast<size_t>(bias) | reinterpret_cast<size_t>(residual) | reinterpret_cast<size_t>(input_bias)) & 15)
     return SIMPB_EINVAL;
   const int ho = (in_h - 1) / stride + 1, wo = (in_w - 1) / stride + 1;
   if (residual_upsample2x && (!residual || (ho & 1) || (wo & 1))) return SIMPB_EINVAL;
@@ -204,6 +215,7 @@ extern "C" int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight
   hipLaunchKernelGGL(conv1x1_f16_kernel, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                      static_cast<_Float16*>(y), static_cast<const _Float16*>(x), static_cast<const _Float16*>(weight),
                      static_cast<const _Float16*>(bias), static_cast<const _Float16*>(residual), (int)p_out, in_channels,
-                     out_channels, relu, stride, ho, wo, in_h, in_w, residual_upsample2x ? 1 : 0);
+                     out_channels, relu, stride, ho, wo, in_h, in_w, residual_upsample2x ? 1 : 0,
+                     static_cast<const _Float16*>(input_bias));
   return simpb_check_launch();
 }

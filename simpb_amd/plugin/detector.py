@@ -54,17 +54,25 @@ class Bottleneck(nn.Module):
         def conv(m, t):
             return F.conv2d(t, m.weight, None, m.stride, m.padding)
 
-        def pointwise(m, t, residual=None, relu=True):
+        def takes(m, t):
+            return (CONV1X1_KERNEL and m.in_channels % 64 == 0 and m.out_channels % 8 == 0 and m.stride[0] in (1, 2)
+                    and m.stride[0] == m.stride[1] and t.is_contiguous(memory_format=torch.channels_last))
+
+        def pointwise(m, t, residual=None, relu=True, input_bias=None):
             # the 1x1 convolutions with their whole epilogue in one launch (csrc/conv1x1.hip); anything the kernel
             # does not take (odd channel counts, an input that is not channels_last) goes the two-launch way
-            if (CONV1X1_KERNEL and m.in_channels % 64 == 0 and m.out_channels % 8 == 0 and m.stride[0] in (1, 2)
-                    and m.stride[0] == m.stride[1] and t.is_contiguous(memory_format=torch.channels_last)):
-                return conv1x1_nhwc(t, m.weight, m.bias, residual, relu, m.stride[0])
+            if takes(m, t):
+                return conv1x1_nhwc(t, m.weight, m.bias, residual, relu, m.stride[0], input_bias=input_bias)
+            assert input_bias is None
             return bias_act_(conv(m, t), m.bias, residual, relu=relu)
 
         identity = x if self.downsample is None else pointwise(self.downsample[0], x, None, relu=False)
         out = pointwise(self.conv1, x)
-        out = bias_act_(conv(self.conv2, out), self.conv2.bias, None, relu=True)
+        out = conv(self.conv2, out)
+        if takes(self.conv3, out) and self.conv3.stride[0] == 1:
+            # conv2's bias + ReLU are applied by conv3 while it stages its input: no epilogue pass for the 3x3 convolution
+            return pointwise(self.conv3, out, identity, relu=True, input_bias=self.conv2.bias)
+        out = bias_act_(out, self.conv2.bias, None, relu=True)
         return pointwise(self.conv3, out, identity, relu=True)
 
 

@@ -335,10 +335,11 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
-def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_upsample2x=False):
+def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_upsample2x=False, input_bias=None):
     """relu?(conv1x1(x, weight, stride) + bias + residual?) for a channels_last f16 tensor, one launch
     (csrc/conv1x1.hip). x [N, Cin, H, W]; weight [Cout, Cin, 1, 1] f16; bias f16 [Cout]. With residual_upsample2x the
-    residual is [N, Cout, H/2, W/2] and is read with nearest-neighbour 2x upsampling (the FPN top-down sum)."""
+    residual is [N, Cout, H/2, W/2] and is read with nearest-neighbour 2x upsampling (the FPN top-down sum). With
+    input_bias (f16 [Cin]) x is first replaced by relu(x + input_bias): the epilogue of the convolution that produced it."""
     _require_gpu(x, weight, bias)
     n, cin, h, w = x.shape
     cout = weight.shape[0]
@@ -353,12 +354,15 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_u
     if residual is not None and (tuple(residual.shape) != tuple(want) or residual.dtype != torch.float16
                                  or not residual.is_contiguous(memory_format=torch.channels_last)):
         raise ValueError("residual must match the output (channels_last f16)")
+    if input_bias is not None and (input_bias.dtype != torch.float16 or input_bias.numel() != cin or not input_bias.is_contiguous()):
+        raise ValueError("input_bias must be a contiguous f16 [Cin] tensor")
     w2 = weight.reshape(cout, cin)
     if not w2.is_contiguous():
         w2 = w2.contiguous()
     status = _lib.lib().simpb_conv1x1_nhwc_f16(_ptr(y), _ptr(x), _ptr(w2), _ptr(bias), _ptr(residual) if residual is not None else None,
                                                n, h, w, cin, cout, stride, 1 if relu else 0,
-                                               1 if residual_upsample2x else 0, _stream())
+                                               1 if residual_upsample2x else 0,
+                                               _ptr(input_bias) if input_bias is not None else None, _stream())
     _lib.check(status, "simpb_conv1x1_nhwc_f16")
     return y
 

@@ -550,3 +550,20 @@ def test_fused_neck_equals_unfused_neck():
     assert float((got[0] - want[0]).abs().max()) <= 2e-2 * scale      # fp16 networks, different rounding points
     assert float((got[0] - want[0]).abs().mean()) <= 2e-3 * scale
     assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+
+
+@gpu
+@pytest.mark.parametrize("cin,cout,h,w,res", [(64, 256, 64, 176, True), (512, 2048, 8, 22, True), (128, 512, 32, 88, False), (192, 40, 5, 7, True)])
+def test_conv1x1_with_input_bias_relu(cin, cout, h, w, res):
+    """conv3 of a bottleneck applying conv2's folded-BN bias + ReLU while it stages its input, against the separate
+    bias_act pass followed by the same kernel (fp32 add, one rounding to fp16 on both routes: bit-exact)."""
+    from simpb_amd.plugin.ops import bias_act_, conv1x1_nhwc
+    g = torch.Generator().manual_seed(cin * 3 + h)
+    x = torch.randn(3, cin, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    b_in = torch.randn(cin, generator=g).half().cuda()
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).half().cuda()
+    b = torch.randn(cout, generator=g).half().cuda()
+    r = torch.randn(3, cout, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last) if res else None
+    want = conv1x1_nhwc(bias_act_(x.clone(), b_in, None, relu=True), wt, b, r, relu=True)
+    got = conv1x1_nhwc(x, wt, b, r, relu=True, input_bias=b_in)
+    assert torch.equal(got, want)
