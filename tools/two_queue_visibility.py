@@ -1,4 +1,5 @@
-"""Stand-alone probe of the eager two-stream hazard of DESIGN.md section 4 (PipelinedRunner.SERIALIZE_EAGER).
+"""Stand-alone probe written in round 1 for the eager two-stream fault. It found nothing because the
+cause was not visibility: tools/daf_stress.py is the probe that reproduces it (a co-running v_mfma_f32_32x32x16_f16 kernel).
 
 Stream B plays the decoder: every iteration it reads a small persistent buffer with `simpb_bank_get` (identity
 ego-motion, zero time step: the output must equal the input), runs some filler kernels and rewrites the buffer with the
