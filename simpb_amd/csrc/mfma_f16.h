@@ -6,7 +6,8 @@
 // OTHER kernels' plain vector arithmetic goes wrong in lanes 48-63 of a wave now and then -- daf_fwd_rows beside a loop of
 // conv1x1 or linear_split: 90-97 % of its launches return wrong channels 192-255 for ~10 anchors; beside fp32-MFMA
 // kernels (linear_f32, hipBLASLt), MIOpen's fp16 3x3 convolution, copies or elementwise kernels: 0 of 1 500. This is
-// what the "eager two-stream fault" of round 1 was. The same product as TWO v_mfma_f32_32x32x8f16 steps (each lane's
+// what the "eager two-stream fault" of round 1 was. A register-only burner (tools/mfma_burn.hip) shows the same for all four
+// double-K 16-bit instructions gfx950 adds (f16 / bf16, 32x32x16 / 16x16x32) and for none of the older ones. The same product as TWO v_mfma_f32_32x32x8f16 steps (each lane's
 // eight k-values split into its low and high four: both operands use the same lane -> k map, so the products pair up
 // and only the summation order changes) does not disturb other waves. SIMPB_MFMA_F16_K16=1 selects the single
 // instruction again (for the measurement above, never for the product).

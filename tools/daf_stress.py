@@ -70,6 +70,26 @@ def main():
     vb = torch.zeros(256, device=dev)
     lv = [torch.randn(6, 256, h, w, device=dev).half().contiguous(memory_format=torch.channels_last) for h, w in shapes]
 
+    BURN = {"f16_32x32x16": 0, "f16_16x16x32": 1, "bf16_32x32x16": 2, "bf16_16x16x32": 3, "f16_32x32x8": 4, "f32_32x32x2": 5,
+            "f16_16x16x16": 6}
+    burn = None
+    if args.co.startswith("burn:"):
+        # a co-runner that only issues one matrix instruction in a loop on registers (tools/mfma_burn.hip, built here)
+        import ctypes
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(os.path.dirname(here), "gpurun_out", "libmfma_burn.so")
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", so,
+                        os.path.join(here, "mfma_burn.hip")], check=True, stderr=subprocess.DEVNULL)
+        blib = ctypes.CDLL(so)
+        blib.mfma_burn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        sink = torch.zeros(4, device=dev)
+
+        def burn(variant):
+            rc = blib.mfma_burn(variant, sink.data_ptr(), 2048, 600, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+
     def co():
         if args.co == "conv1x1":
             ops.conv1x1_nhwc(cx, cw1, cb, None, True, 1)
@@ -87,6 +107,8 @@ def main():
             ops.bias_act_(cx, cb, None, True)
         elif args.co == "format":
             ops.format_tokens(lv, 1, 6)
+        elif args.co.startswith("burn:"):
+            burn(BURN[args.co[5:]])
         elif args.co != "none":
             raise SystemExit("unknown --co")
 
