@@ -90,6 +90,33 @@ def main():
             rc = blib.mfma_burn(variant, sink.data_ptr(), 2048, 600, torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
 
+    gx = gw = None
+    gstride = gk = 1
+    if args.co.startswith("conv:"):  # conv:cin,cout,h,w,k,stride  (fp16 channels_last, 6 images, as MIOpen picks the kernel)
+        cin, cout, h, w_, gk, gstride = (int(v) for v in args.co[5:].split(","))
+        torch.backends.cudnn.benchmark = True
+        gx = torch.randn(6, cin, h, w_, device=dev).half().contiguous(memory_format=torch.channels_last)
+        gw = (torch.randn(cout, cin, gk, gk, device=dev) * 0.02).half().contiguous(memory_format=torch.channels_last)
+        for _ in range(3):
+            F.conv2d(gx, gw, None, stride=gstride, padding=gk // 2)
+        torch.cuda.synchronize()
+    bb_model = bb_img = None
+    if args.co == "backbone":
+        # the shipped backbone + FPN + token format + value projections exactly as the runner's backbone stream runs them
+        # (vendor 3x3 / 7x7 convolutions as MIOpen picks them on this box, our conv1x1 / value_proj): the whole co-runner
+        from simpb_amd import configs, plugin, synth
+        cfg = configs.simpb_plus(anchor=synth.anchors(900))
+        bb_model = plugin.build_detector(cfg["model"]).eval()
+        synth.load_procedural(bb_model)
+        bb_model = bb_model.cuda().fuse_conv_bn().half_backbone()
+        bb_img = synth.images(1, 0, (704, 256)).cuda()
+        torch.backends.cudnn.benchmark = True
+        with torch.no_grad():
+            for _ in range(3):
+                fm = bb_model.extract_feat(bb_img)
+                bb_model.head.precompute_values(list(fm))
+        torch.cuda.synchronize()
+
     def co():
         if args.co == "conv1x1":
             ops.conv1x1_nhwc(cx, cw1, cb, None, True, 1)
@@ -109,6 +136,13 @@ def main():
             ops.format_tokens(lv, 1, 6)
         elif args.co.startswith("burn:"):
             burn(BURN[args.co[5:]])
+        elif args.co.startswith("conv:"):
+            F.conv2d(gx, gw, None, stride=gstride, padding=gk // 2)
+        elif args.co == "maxpool":
+            F.max_pool2d(cx, 3, 2, 1)
+        elif args.co == "backbone":
+            with torch.no_grad():
+                bb_model.extract_feat(bb_img)
         elif args.co != "none":
             raise SystemExit("unknown --co")
 
@@ -118,7 +152,7 @@ def main():
     torch.cuda.synchronize()
     for it in range(args.launches):
         with torch.cuda.stream(s_co):
-            for _ in range(3):
+            for _ in range(1 if args.co == "backbone" else 3):
                 co()
         with torch.cuda.stream(s_daf):
             out = daf()
