@@ -194,6 +194,25 @@ int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const voi
                            int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride, int relu,
                            int residual_upsample2x, const void* input_bias, void* stream);
 
+/* A whole BN-folded 3x3 convolution (padding 1) of the fp16 channels_last backbone in one launch, as an implicit GEMM:
+ *   out[n, ho, wo, :] = relu?( sum_{dy,dx} x[n, ho*stride + dy - 1, wo*stride + dx - 1, :] . weight[:, dy, dx, :]^T + bias )
+ * x f16 [num_images, in_h, in_w, in_channels] (NHWC), weight f16 [out_channels, 3, 3, in_channels] (what PyTorch keeps for a
+ * channels_last Conv2d weight), bias f16 [out_channels]; fp32 accumulate, one rounding to f16. Exactly one destination:
+ *   y      f16 [num_images, ho, wo, out_channels], ho = (in_h - 1) / stride + 1, or
+ *   tokens f32: the decoder's token buffer col_feats [bs, cams * tokens_per_cam, out_channels] of feature_maps_format
+ *          (projects/mmdet3d_plugin/ops/__init__.py:63-92); image n is camera block n, this level's pixels start at row
+ *          level_start of the block; the value written is the f16 result widened to f32 (what a separate format pass over
+ *          the f16 map would write): the FPN's output convolutions produce the tokens themselves.
+ * These are conv2 of every ResNet bottleneck and FPN.fpn_convs (mmdet ResNet + FPN of
+ * projects/configs/simpb_nus_r50_img_704x256.py:79-99 after tools/fuse_conv_bn.py:10-48). stride 1 or 2;
+ * in_channels % 64 == 0, out_channels % 8 == 0; 16-byte aligned. variant 0 = choose the tiling from the shape; 1-6 force one
+ * (pixels x channels per workgroup: 1 = 128 x 64 and 2 = 256 x 64 with the activations read straight into the MFMA layout;
+ * 3 = 32 x 64 and 4 = 64 x 64 with K split over the workgroup's waves; 5 = 128 x 64 and 6 = 128 x 128 with both operands
+ * staged through LDS) -- all give the same sums up to fp32 summation order. */
+int simpb_conv3x3_nhwc_f16(void* y, float* tokens, int tokens_per_cam, int level_start, const void* x, const void* weight,
+                           const void* bias, int num_images, int in_h, int in_w, int in_channels, int out_channels,
+                           int stride, int relu, int variant, void* stream);
+
 /* Attention core of torch.nn.MultiheadAttention (between in_proj and out_proj), exact fp32, flash
  * style, head_dim = 64: out[b,q,h*64+d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d].
  * q/k/v/out are [batch, N, heads*64] with row strides ldq/ldk/ldv/ldo (floats; batches are N*ld apart),

@@ -20,6 +20,10 @@ __all__ = ["SimPB", "ResNet", "FPN"]
 # True: conv1 / conv3 / downsample of the fp16 bottlenecks run as csrc/conv1x1.hip (one launch each, epilogue
 # included); False: vendor convolution + csrc/bias_act.hip (two launches), also the cross-check in tests.
 CONV1X1_KERNEL = True
+# True: conv2 of the fp16 bottlenecks and the FPN's output convolutions run as csrc/conv3x3.hip (implicit GEMM, epilogue
+# included; the FPN's write the decoder's fp32 tokens themselves); False: vendor convolution (+ csrc/bias_act.hip / the
+# token format pass), also the cross-check in tests.
+CONV3X3_KERNEL = True
 
 
 class Bottleneck(nn.Module):
@@ -49,7 +53,7 @@ class Bottleneck(nn.Module):
     def _forward_fused(self, x):
         """BN already folded (SimPB.fuse_conv_bn): convolutions run without bias and each is followed
         by ONE epilogue kernel (bias [+ residual] [+ ReLU]) instead of add_, add and relu_."""
-        from .ops import bias_act_, conv1x1_nhwc
+        from .ops import bias_act_, conv1x1_nhwc, conv3x3_nhwc
 
         def conv(m, t):
             return F.conv2d(t, m.weight, None, m.stride, m.padding)
@@ -68,7 +72,13 @@ class Bottleneck(nn.Module):
 
         identity = x if self.downsample is None else pointwise(self.downsample[0], x, None, relu=False)
         out = pointwise(self.conv1, x)
-        out = conv(self.conv2, out)
+        c2 = self.conv2
+        if (CONV3X3_KERNEL and c2.in_channels % 64 == 0 and c2.out_channels % 8 == 0 and c2.stride[0] in (1, 2)
+                and c2.stride[0] == c2.stride[1] and c2.padding == (1, 1) and out.is_contiguous(memory_format=torch.channels_last)):
+            # the 3x3 convolution as one implicit-GEMM launch with its bias + ReLU (csrc/conv3x3.hip)
+            out = conv3x3_nhwc(out, c2.weight, c2.bias, relu=True, stride=c2.stride[0])
+            return pointwise(self.conv3, out, identity, relu=True)
+        out = conv(c2, out)
         if takes(self.conv3, out) and self.conv3.stride[0] == 1:
             # conv2's bias + ReLU are applied by conv3 while it stages its input: no epilogue pass for the 3x3 convolution
             return pointwise(self.conv3, out, identity, relu=True, input_bias=self.conv2.bias)
@@ -180,12 +190,34 @@ class FPN(BaseModule):
                     else:
                         up = F.interpolate(laterals[i + 1], size=xin.shape[2:], **self.upsample_cfg)
                 laterals[i] = conv1x1_nhwc(xin, conv.weight, conv.bias, up, relu=False, residual_upsample2x=up2x)
+            tokens_for = getattr(self, "tokens_for", None)   # (bs, num_cams) set by SimPB.extract_feat for this call
+            self.wrote_tokens = None
+            if (CONV3X3_KERNEL and tokens_for is not None
+                    and all(m.conv.in_channels % 64 == 0 and m.conv.out_channels % 8 == 0 and m.conv.padding == (1, 1)
+                            and m.conv.stride == (1, 1) and m.conv.bias is not None for m in self.fpn_convs)):
+                # the output convolutions write the decoder's fp32 token buffer themselves (csrc/conv3x3.hip): no f16 maps,
+                # no format pass (feature_maps_format, ops/__init__.py:63-92)
+                from .ops import conv3x3_nhwc, token_tables
+                bs, num_cams = tokens_for
+                shapes = tuple(tuple(t.shape[-2:]) for t in laterals)
+                per_cam = sum(h * w for h, w in shapes)
+                cout = self.fpn_convs[0].conv.out_channels
+                col = torch.empty(bs, num_cams * per_cam, cout, device=x0.device, dtype=torch.float32)
+                start = 0
+                for i in range(n):
+                    conv = self.fpn_convs[i].conv
+                    conv3x3_nhwc(laterals[i], conv.weight, conv.bias, relu=False, tokens=(col, per_cam, start))
+                    start += shapes[i][0] * shapes[i][1]
+                self.deferred_output_bias = False
+                self.wrote_tokens = [col, *token_tables(shapes, num_cams, col.device)]
+                return ()
             self.deferred_output_bias = bool(getattr(self, "defer_output_bias", False))
             if self.deferred_output_bias:
                 # the caller (SimPB.extract_feat) adds the biases while it writes the tokens (ops.format_tokens)
                 return tuple(F.conv2d(laterals[i], self.fpn_convs[i].conv.weight, None, padding=1) for i in range(n))
             return tuple(self.fpn_convs[i](laterals[i]) for i in range(n))
         self.deferred_output_bias = False
+        self.wrote_tokens = None
         laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
         for i in range(len(laterals) - 1, 0, -1):
             laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
@@ -273,7 +305,11 @@ class SimPB(BaseModule):
                      and all(m.conv.bias is not None and m.conv.bias.dtype == torch.float16 and m.conv.padding == (1, 1)
                              and m.conv.out_channels % 8 == 0 for m in self.img_neck.fpn_convs))
             self.img_neck.defer_output_bias = defer
+            self.img_neck.tokens_for = (bs, num_cams) if defer and feature_maps[0].shape[0] == bs * num_cams else None
             feature_maps = list(self.img_neck(feature_maps))
+            if getattr(self.img_neck, "wrote_tokens", None) is not None:
+                tokens, self.img_neck.wrote_tokens = self.img_neck.wrote_tokens, None
+                return tokens
             if getattr(self.img_neck, "deferred_output_bias", False):  # (False when the neck took its unfused route)
                 biases = [m.conv.bias for m in self.img_neck.fpn_convs]
         if feature_maps[0].is_cuda and feature_maps[0].shape[1] % 8 == 0:

@@ -153,6 +153,11 @@ def _shape_tables(shapes, num_cams, device):
     return _table_cache[key]
 
 
+def token_tables(shapes, num_cams, device):
+    """(spatial_shape, scale_start_index) of feature_maps_format (ops/__init__.py:80-90) for level shapes ((h, w), ...)."""
+    return _shape_tables(tuple(tuple(s) for s in shapes), num_cams, device)
+
+
 def query_cam_from_groups(query_groups, num_query, device):
     """[(start, end)] * num_cams (allocation.py:99) -> i32[num_query] camera id per query slot."""
     cam = torch.zeros(num_query, dtype=torch.int32)
@@ -364,6 +369,37 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_u
                                                1 if residual_upsample2x else 0,
                                                _ptr(input_bias) if input_bias is not None else None, _stream())
     _lib.check(status, "simpb_conv1x1_nhwc_f16")
+    return y
+
+
+def conv3x3_nhwc(x, weight, bias, relu=True, stride=1, tokens=None, variant=0):
+    """relu?(conv3x3(x, weight, stride, padding=1) + bias) for a channels_last f16 tensor, one launch (csrc/conv3x3.hip).
+    x [N, Cin, H, W]; weight f16 [Cout, Cin, 3, 3] (channels_last, i.e. [Cout][3][3][Cin] in memory); bias f16 [Cout].
+    tokens = (col_feats f32 [bs, cams * tokens_per_cam, Cout], tokens_per_cam, level_start): the result is written as
+    fp32 token rows of this level (feature_maps_format layout) instead of a map, and None is returned."""
+    _require_gpu(x, weight, bias)
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    if (x.dtype != torch.float16 or not x.is_contiguous(memory_format=torch.channels_last) or weight.dtype != torch.float16
+            or bias.dtype != torch.float16 or tuple(weight.shape) != (cout, cin, 3, 3) or cin % 64 or cout % 8
+            or stride not in (1, 2) or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError("conv3x3_nhwc takes channels_last f16 input, f16 [Cout, Cin, 3, 3] weight, Cin % 64 == 0, Cout % 8 == 0")
+    if not weight.is_contiguous(memory_format=torch.channels_last):
+        weight = weight.contiguous(memory_format=torch.channels_last)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    if tokens is None:
+        y = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float16, memory_format=torch.channels_last)
+        col, per_cam, start = None, 0, 0
+    else:
+        col, per_cam, start = tokens
+        y = None
+        if (col.dtype != torch.float32 or not col.is_contiguous() or col.shape[-1] != cout or col.numel() != n * per_cam * cout
+                or start < 0 or start + ho * wo > per_cam):
+            raise ValueError("tokens: (contiguous f32 [bs, cams * tokens_per_cam, Cout] with bs * cams == N, tokens_per_cam, level_start)")
+    status = _lib.lib().simpb_conv3x3_nhwc_f16(_ptr(y) if y is not None else None, _ptr(col) if col is not None else None,
+                                               per_cam, start, _ptr(x), _ptr(weight), _ptr(bias), n, h, w, cin, cout, stride,
+                                               1 if relu else 0, variant, _stream())
+    _lib.check(status, "simpb_conv3x3_nhwc_f16")
     return y
 
 

@@ -486,6 +486,60 @@ def test_conv1x1_kernel_vs_conv2d(cin, cout, h, w, stride, res, relu):
 
 
 @gpu
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cin,cout,h,w,stride,relu", [
+    (64, 64, 64, 176, 1, True),       # layer1 conv2
+    (128, 128, 64, 176, 2, True),     # layer2.0 conv2, stride 2
+    (256, 256, 16, 44, 1, True),      # layer3 conv2
+    (512, 512, 8, 22, 1, True),       # layer4 conv2: 72 chunks, small map
+    (256, 256, 32, 88, 1, False),     # FPN output convolution (no ReLU)
+    (192, 40, 5, 7, 2, True),         # ragged pixels / channels, odd sizes with stride 2, 27 chunks
+    (64, 72, 3, 3, 1, False),         # a map smaller than one tile row, second channel block partial
+])
+def test_conv3x3_kernel_vs_conv2d(cin, cout, h, w, stride, relu, variant):
+    """csrc/conv3x3.hip (every tiling) against F.conv2d(padding=1) + bias (+ ReLU) evaluated in fp32 on the same fp16
+    values (mmdet ResNet bottleneck conv2 / FPN.fpn_convs after tools/fuse_conv_bn.py:10-48): fp32 accumulate, one
+    rounding, so within one fp16 rounding of that reference. Zero padding, stride 2 and image borders are where an
+    implicit GEMM goes wrong, hence the small odd shapes; 3 images so that a tile crosses image boundaries."""
+    from simpb_amd.plugin.ops import conv3x3_nhwc
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(3, cin, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).half().cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(cout, generator=g).half().cuda()
+    want = F.conv2d(x.float(), wt.float(), b.float(), stride=stride, padding=1)
+    if relu:
+        want = want.relu()
+    got = conv3x3_nhwc(x, wt, b, relu, stride, variant=variant)
+    assert got.shape == want.shape and got.dtype == torch.float16 and got.is_contiguous(memory_format=torch.channels_last)
+    err = (got.float() - want).abs()
+    assert float((err - 1e-3 * want.abs()).max()) <= 2e-3
+
+
+@gpu
+def test_conv3x3_writes_tokens():
+    """FPN.fpn_convs writing the decoder's token buffer themselves: each level's convolution with `tokens` must leave in
+    col_feats exactly what feature_maps_format (ops/__init__.py:63-92) makes of the f16 maps the same kernel writes."""
+    from simpb_amd.plugin.ops import conv3x3_nhwc, feature_maps_format
+    g = torch.Generator().manual_seed(5)
+    bs, cams, c = 2, 3, 256
+    shapes = [(16, 44), (8, 22), (4, 11), (2, 6)]
+    per_cam = sum(h * w for h, w in shapes)
+    col = torch.full((bs, cams * per_cam, c), float("nan"), device="cuda")
+    maps, start = [], 0
+    for h, w in shapes:
+        x = torch.randn(bs * cams, c, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(c, c, 3, 3, generator=g) / 48).half().cuda().contiguous(memory_format=torch.channels_last)
+        b = torch.randn(c, generator=g).half().cuda()
+        maps.append(conv3x3_nhwc(x, wt, b, relu=False))
+        assert conv3x3_nhwc(x, wt, b, relu=False, tokens=(col, per_cam, start)) is None
+        start += h * w
+    want = feature_maps_format([m.float().reshape(bs, cams, c, *m.shape[2:]) for m in maps])[0]
+    assert torch.equal(col, want)
+    with pytest.raises(ValueError):
+        conv3x3_nhwc(x, wt, b, relu=False, tokens=(col, per_cam, per_cam - 1))   # level does not fit its block
+
+
+@gpu
 @pytest.mark.parametrize("cin,cout,h,w", [(512, 256, 32, 88), (256, 256, 64, 176), (1024, 256, 16, 44), (192, 40, 6, 10)])
 def test_conv1x1_with_upsampled_residual(cin, cout, h, w):
     """The FPN top-down sum lateral[i-1] = conv1x1(c[i-1]) + interpolate(lateral[i], nearest) (mmdet FPN.forward) with
@@ -537,15 +591,22 @@ def test_fused_neck_equals_unfused_neck():
     model = model.cuda().fuse_conv_bn().half_backbone()
     img = synth.images(1, 1, (352, 128)).cuda()
     with torch.no_grad():
-        got = model.extract_feat(img)
-        assert model.img_neck.deferred_output_bias
-        old = detector.CONV1X1_KERNEL
+        got = model.extract_feat(img)           # conv1x1 + conv3x3 kernels, the FPN writes the tokens itself
+        assert not model.img_neck.deferred_output_bias
+        old = detector.CONV1X1_KERNEL, detector.CONV3X3_KERNEL
         try:
-            detector.CONV1X1_KERNEL = False   # mmdet's statement: lateral convs, F.interpolate, adds, biased 3x3 convs
+            detector.CONV3X3_KERNEL = False      # vendor 3x3 convolutions, biases added by the token format pass
+            mid = model.extract_feat(img)
+            assert model.img_neck.deferred_output_bias
+            detector.CONV1X1_KERNEL = False      # mmdet's statement: lateral convs, F.interpolate, adds, biased 3x3 convs
             want = model.extract_feat(img)
         finally:
-            detector.CONV1X1_KERNEL = old
+            detector.CONV1X1_KERNEL, detector.CONV3X3_KERNEL = old
         assert not model.img_neck.deferred_output_bias
+    scale = float(want[0].abs().max())
+    assert float((mid[0] - want[0]).abs().max()) <= 2e-2 * scale
+    assert float((mid[0] - want[0]).abs().mean()) <= 2e-3 * scale
+    assert torch.equal(mid[1], want[1]) and torch.equal(mid[2], want[2])
     scale = float(want[0].abs().max())
     assert float((got[0] - want[0]).abs().max()) <= 2e-2 * scale      # fp16 networks, different rounding points
     assert float((got[0] - want[0]).abs().mean()) <= 2e-3 * scale
