@@ -111,6 +111,12 @@ int simpb_linear_f32(float* y, const float* x, const float* weight, const float*
 int simpb_linear_f16x3(float* y, const float* x, const void* weight_hi, const void* weight_lo, const float* bias, int M,
                        int N, int K, void* stream);
 
+/* The same product for an x that is already half precision (f16 [M, K]; e.g. the camera tokens as the fp16 backbone
+ * produced them, simpb.py:63): its trailing part is zero, so y = x.W_hi^T + (x.W_lo^T) / 2048 + bias in two passes with the
+ * error of the three-pass form, half the bytes of x and no splitting arithmetic. K % 64 == 0; 16-byte aligned. */
+int simpb_linear_f16in_split(float* y, const void* x_f16, const void* weight_hi, const void* weight_lo, const float* bias,
+                             int M, int N, int K, void* stream);
+
 /* Grouped small GEMM of the decoder: up to 4 independent problems per launch, each
  *   y[M, 0:N] (row stride ldy) = relu?( [x0 | x1 | ...][M, K] . w[N, K]^T (row stride ldw) + bias[N] )
  * where x is given as up to 4 column segments (pointer, row stride, width; widths sum to K). This is
@@ -202,16 +208,17 @@ int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const voi
  *   tokens f32: the decoder's token buffer col_feats [bs, cams * tokens_per_cam, out_channels] of feature_maps_format
  *          (projects/mmdet3d_plugin/ops/__init__.py:63-92); image n is camera block n, this level's pixels start at row
  *          level_start of the block; the value written is the f16 result widened to f32 (what a separate format pass over
- *          the f16 map would write): the FPN's output convolutions produce the tokens themselves.
+ *          the f16 map would write): the FPN's output convolutions produce the tokens themselves. tokens_f16 (f16, same
+ *          layout, or NULL): the same rows without the widening, for simpb_linear_f16in_split (value_proj).
  * These are conv2 of every ResNet bottleneck and FPN.fpn_convs (mmdet ResNet + FPN of
  * projects/configs/simpb_nus_r50_img_704x256.py:79-99 after tools/fuse_conv_bn.py:10-48). stride 1 or 2;
  * in_channels % 64 == 0, out_channels % 8 == 0; 16-byte aligned. variant 0 = choose the tiling from the shape; 1-6 force one
  * (pixels x channels per workgroup: 1 = 128 x 64 and 2 = 256 x 64 with the activations read straight into the MFMA layout;
  * 3 = 32 x 64 and 4 = 64 x 64 with K split over the workgroup's waves; 5 = 128 x 64 and 6 = 128 x 128 with both operands
  * staged through LDS) -- all give the same sums up to fp32 summation order. */
-int simpb_conv3x3_nhwc_f16(void* y, float* tokens, int tokens_per_cam, int level_start, const void* x, const void* weight,
-                           const void* bias, int num_images, int in_h, int in_w, int in_channels, int out_channels,
-                           int stride, int relu, int variant, void* stream);
+int simpb_conv3x3_nhwc_f16(void* y, float* tokens, void* tokens_f16, int tokens_per_cam, int level_start, const void* x,
+                           const void* weight, const void* bias, int num_images, int in_h, int in_w, int in_channels,
+                           int out_channels, int stride, int relu, int variant, void* stream);
 
 /* Attention core of torch.nn.MultiheadAttention (between in_proj and out_proj), exact fp32, flash
  * style, head_dim = 64: out[b,q,h*64+d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d].

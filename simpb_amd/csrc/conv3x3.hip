@@ -46,6 +46,7 @@ constexpr int kSmemBytes = kStageBytes > kTileBytes ? kStageBytes : kTileBytes;
 struct ConvArgs {
   _Float16* y;            // f16 [P_out, Cout] or NULL
   float* tok;             // f32 token buffer or NULL (ops/__init__.py:63-92 layout: [bs, cams * tokens_per_cam, Cout])
+  _Float16* tok16;        // the same rows in f16 (for value_proj's two-pass product) or NULL
   const _Float16 *x, *w, *bias;
   int P_out, Cin, Cout, relu, stride, Ho, Wo, H, W;
   int tokens_per_cam, level_start;
@@ -76,6 +77,7 @@ __device__ __forceinline__ void emit_piece(const ConvArgs& a, int c0, int p, int
       float* d = a.tok + trow + c0 + c8;
       *reinterpret_cast<float4*>(d) = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
       *reinterpret_cast<float4*>(d + 4) = make_float4((float)o[4], (float)o[5], (float)o[6], (float)o[7]);
+      if (a.tok16) *reinterpret_cast<h16x8*>(a.tok16 + trow + c0 + c8) = o;
     } else {
       *reinterpret_cast<h16x8*>(a.y + (size_t)p * a.Cout + c0 + c8) = o;
     }
@@ -86,8 +88,12 @@ __device__ __forceinline__ void emit_piece(const ConvArgs& a, int c0, int p, int
       if (c < a.Cout) {
         const float t = v[e] + (float)a.bias[c];
         const _Float16 o = (_Float16)(a.relu ? fmaxf(t, 0.f) : t);
-        if (a.tok) a.tok[trow + c] = (float)o;
-        else a.y[(size_t)p * a.Cout + c] = o;
+        if (a.tok) {
+          a.tok[trow + c] = (float)o;
+          if (a.tok16) a.tok16[trow + c] = o;
+        } else {
+          a.y[(size_t)p * a.Cout + c] = o;
+        }
       }
     }
   }
@@ -491,10 +497,10 @@ void launch_staged(ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int simpb_conv3x3_nhwc_f16(void* y, float* tokens, int tokens_per_cam, int level_start, const void* x,
-                                      const void* weight, const void* bias, int num_images, int in_h, int in_w,
+extern "C" int simpb_conv3x3_nhwc_f16(void* y, float* tokens, void* tokens_f16, int tokens_per_cam, int level_start,
+                                      const void* x, const void* weight, const void* bias, int num_images, int in_h, int in_w,
                                       int in_channels, int out_channels, int stride, int relu, int variant, void* stream) {
-  if ((!y && !tokens) || (y && tokens) || !x || !weight || !bias || num_images <= 0 || in_h <= 0 || in_w <= 0 ||
+  if ((!y && !tokens) || (y && tokens) || (tokens_f16 && !tokens) || (reinterpret_cast<size_t>(tokens_f16) & 15) || !x || !weight || !bias || num_images <= 0 || in_h <= 0 || in_w <= 0 ||
       in_channels <= 0 || out_channels <= 0 || (stride != 1 && stride != 2) || in_channels % BK != 0 || out_channels % 8 != 0 ||
       variant < 0 || variant > 6)
     return SIMPB_EINVAL;
@@ -507,7 +513,7 @@ extern "C" int simpb_conv3x3_nhwc_f16(void* y, float* tokens, int tokens_per_cam
   if (p_out > (1ll << 30) || in_elems > (1ll << 31) - 1) return SIMPB_EINVAL;   // tap offsets are 32-bit
   if (tokens && (tokens_per_cam < ho * wo || level_start < 0 || level_start + ho * wo > tokens_per_cam)) return SIMPB_EINVAL;
   (void)hipGetLastError();
-  ConvArgs a{static_cast<_Float16*>(y), tokens, static_cast<const _Float16*>(x), static_cast<const _Float16*>(weight),
+  ConvArgs a{static_cast<_Float16*>(y), tokens, static_cast<_Float16*>(tokens_f16), static_cast<const _Float16*>(x), static_cast<const _Float16*>(weight),
              static_cast<const _Float16*>(bias), (int)p_out, in_channels, out_channels, relu, stride, ho, wo, in_h, in_w,
              tokens_per_cam, level_start, 0, 0, 0};
   const long long ny = (out_channels + BN - 1) / BN;

@@ -204,7 +204,7 @@ extern "C" int simpb_deformable_aggregation_forward(
 
 // 2: simpb_mlp_chain gained the post stage (8 chains per launch); 3: simpb_bank_cache takes the hold flags, the 3D
 // record carries the int64 track id in two lanes (15 columns)
-extern "C" int simpb_abi_version(void) { return 3; }
+extern "C" int simpb_abi_version(void) { return 4; }
 
 // ---- optional per-launch HIP-event timing (bench.py's roofline leg). Events are recorded on the
 // launch stream immediately around the kernel launch, inside the same C call, so the interval

@@ -20,6 +20,7 @@
 // and that, not the matrix pipe, set the time: 123 us.)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <type_traits>
 #include "../../include/simpb_hip.h"
 #include "mfma_f16.h"
 
@@ -139,6 +140,128 @@ __global__ __launch_bounds__(kThreads) void linear_f16x3_kernel(float* __restric
   }
 }
 
+
+// ---- the same product when x is ALREADY half precision --------------------------------------------------------------------
+// The camera tokens value_proj reads are the output of the fp16 backbone widened to fp32 (simpb.py:63 `out_fp32`), so their
+// trailing part is exactly zero and  x . W^T = x.Wh^T + (x.Wl^T) / 2048  with the same error as the three-pass form: two
+// passes instead of three, half the bytes of x, and no splitting arithmetic. csrc/conv3x3.hip leaves the tokens in both
+// forms (`tokens_f16`). Pipeline of csrc/conv3x3.hip's staged kernel: 128 rows x 64 output columns per workgroup (B tile =
+// the 64 rows of Wh and the 64 rows of Wl), 4 waves as 2 x 2, each 64 rows x 32 columns with a leading and a trailing
+// accumulator; K in chunks of 64 through a double-buffered LDS stage, three register sets, one barrier per chunk.
+namespace h2 {
+constexpr int BMt = 128, BNo = 64, BKc = 64;
+constexpr int LDHc = BKc + 8;
+constexpr int kRows = BMt + 2 * BNo;
+constexpr int kThreads2 = 256;
+
+struct Args {
+  float* y;
+  const _Float16 *x, *wh, *wl;
+  const float* bias;
+  int M, N, K, gx, gy, per_xcd;
+};
+
+template <int S>
+using IC = std::integral_constant<int, S>;
+
+__global__ __launch_bounds__(kThreads2, 2) void linear_h2_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) _Float16 s_ab[2 * kRows * LDHc];
+  const int tile = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= a.per_xcd || tile >= a.gx * a.gy) return;
+  const int tx = tile / a.gy, ty = tile - tx * a.gy;   // column blocks of one row block next to each other (same XCD: x from L2)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, kb = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int row0 = tx * BMt, col0 = ty * BNo;
+  const int K = a.K, nchunks = K / BKc;
+
+  const int sr = tid >> 3, sc = (tid & 7) * 8;
+  size_t xrow[4], wrow[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xrow[i] = (size_t)min(row0 + sr + 32 * i, a.M - 1) * K + sc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) wrow[i] = (size_t)min(col0 + sr + 32 * i, a.N - 1) * K + sc;
+  h16x8 rx[3][4], rh[3][2], rl[3][2];
+  auto fetch = [&](auto set_c, int chunk) __attribute__((always_inline)) {
+    constexpr int s = decltype(set_c)::value;
+    const int k0 = min(chunk, nchunks - 1) * BKc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rx[s][i] = *reinterpret_cast<const h16x8*>(a.x + xrow[i] + k0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rh[s][i] = *reinterpret_cast<const h16x8*>(a.wh + wrow[i] + k0);
+      rl[s][i] = *reinterpret_cast<const h16x8*>(a.wl + wrow[i] + k0);
+    }
+  };
+  auto stash = [&](auto set_c, int buf) __attribute__((always_inline)) {
+    constexpr int s = decltype(set_c)::value;
+    _Float16* base = s_ab + buf * kRows * LDHc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<h16x8*>(&base[(sr + 32 * i) * LDHc + sc]) = rx[s][i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<h16x8*>(&base[(BMt + sr + 32 * i) * LDHc + sc]) = rh[s][i];
+      *reinterpret_cast<h16x8*>(&base[(BMt + BNo + sr + 32 * i) * LDHc + sc]) = rl[s][i];
+    }
+  };
+  f32x16 acc[2], acs[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[m][r] = 0.f; acs[m][r] = 0.f; }
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
+    const _Float16* base = s_ab + buf * kRows * LDHc + 8 * kb;
+    const _Float16* sa = base + (wm * 64 + r32) * LDHc;
+    const _Float16* sh = base + (BMt + wn * 32 + r32) * LDHc;
+    const _Float16* sl = base + (BMt + BNo + wn * 32 + r32) * LDHc;
+#pragma unroll
+    for (int ks = 0; ks < BKc / 16; ++ks) {
+      const h16x8 a0 = *reinterpret_cast<const h16x8*>(sa + 16 * ks);
+      const h16x8 a1 = *reinterpret_cast<const h16x8*>(sa + 32 * LDHc + 16 * ks);
+      const h16x8 bh = *reinterpret_cast<const h16x8*>(sh + 16 * ks);
+      const h16x8 bl = *reinterpret_cast<const h16x8*>(sl + 16 * ks);
+      acc[0] = simpb::mfma_32x32x16_f16(a0, bh, acc[0]);
+      acs[0] = simpb::mfma_32x32x16_f16(a0, bl, acs[0]);
+      acc[1] = simpb::mfma_32x32x16_f16(a1, bh, acc[1]);
+      acs[1] = simpb::mfma_32x32x16_f16(a1, bl, acs[1]);
+    }
+  };
+  fetch(IC<0>{}, 0);
+  fetch(IC<1>{}, 1);
+  fetch(IC<2>{}, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  stash(IC<0>{}, 0);
+  __syncthreads();
+  auto step = [&](auto cur, auto nxt, int c) __attribute__((always_inline)) {
+    fetch(cur, c + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    stash(nxt, (c + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(c & 1);
+    __syncthreads();
+  };
+  for (int c = 0; c < nchunks; c += 3) {
+    step(IC<0>{}, IC<1>{}, c);
+    if (c + 1 < nchunks) step(IC<1>{}, IC<2>{}, c + 1);
+    if (c + 2 < nchunks) step(IC<2>{}, IC<0>{}, c + 2);
+  }
+  // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): a store
+  // instruction writes two whole 128-byte lines
+  const int gc = col0 + wn * 32 + r32;
+  if (gc < a.N) {
+    const float bv = a.bias ? a.bias[gc] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gr = row0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        if (gr < a.M) a.y[(size_t)gr * a.N + gc] = acc[m][r] + acs[m][r] * (1.f / 2048.f) + bv;
+      }
+  }
+}
+}  // namespace h2
+
 }  // namespace
 
 extern "C" int simpb_linear_f16x3(float* y, const float* x, const void* weight_hi, const void* weight_lo, const float* bias,
@@ -151,5 +274,23 @@ extern "C" int simpb_linear_f16x3(float* y, const float* x, const void* weight_h
   if (grid.y > 65535) return SIMPB_EINVAL;
   hipLaunchKernelGGL(linear_f16x3_kernel, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream), y, x,
                      static_cast<const _Float16*>(weight_hi), static_cast<const _Float16*>(weight_lo), bias, M, N, K);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_linear_f16in_split(float* y, const void* x_f16, const void* weight_hi, const void* weight_lo,
+                                        const float* bias, int M, int N, int K, void* stream) {
+  if (!y || !x_f16 || !weight_hi || !weight_lo || M <= 0 || N <= 0 || K <= 0 || K % h2::BKc != 0) return SIMPB_EINVAL;
+  if ((reinterpret_cast<size_t>(x_f16) | reinterpret_cast<size_t>(weight_hi) | reinterpret_cast<size_t>(weight_lo)) & 15)
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  h2::Args a{y, static_cast<const _Float16*>(x_f16), static_cast<const _Float16*>(weight_hi),
+             static_cast<const _Float16*>(weight_lo), bias, M, N, K, 0, 0, 0};
+  a.gx = (M + h2::BMt - 1) / h2::BMt;
+  a.gy = (N + h2::BNo - 1) / h2::BNo;
+  const long long total = (long long)a.gx * a.gy;
+  if (total > (1ll << 28)) return SIMPB_EINVAL;
+  a.per_xcd = (int)((total + 7) / 8);
+  hipLaunchKernelGGL(h2::linear_h2_kernel, dim3((unsigned)(a.per_xcd * 8)), dim3(h2::kThreads2), 0,
+                     static_cast<hipStream_t>(stream), a);
   return simpb_check_launch();
 }

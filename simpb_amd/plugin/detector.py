@@ -203,11 +203,14 @@ class FPN(BaseModule):
                 per_cam = sum(h * w for h, w in shapes)
                 cout = self.fpn_convs[0].conv.out_channels
                 col = torch.empty(bs, num_cams * per_cam, cout, device=x0.device, dtype=torch.float32)
+                # the same rows without the widening: value_proj (group_attn.py:176) reads these (two-pass split product)
+                col16 = torch.empty(bs, num_cams * per_cam, cout, device=x0.device, dtype=torch.float16)
                 start = 0
                 for i in range(n):
                     conv = self.fpn_convs[i].conv
-                    conv3x3_nhwc(laterals[i], conv.weight, conv.bias, relu=False, tokens=(col, per_cam, start))
+                    conv3x3_nhwc(laterals[i], conv.weight, conv.bias, relu=False, tokens=(col, per_cam, start, col16))
                     start += shapes[i][0] * shapes[i][1]
+                col.simpb_f16 = col16
                 self.deferred_output_bias = False
                 self.wrote_tokens = [col, *token_tables(shapes, num_cams, col.device)]
                 return ()

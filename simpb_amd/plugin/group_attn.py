@@ -105,6 +105,9 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
         # fp32-grade product on the FP16 matrix cores (three split passes); the camera tokens are the output of
         # the fp16 backbone, well inside the half-precision range the split needs
         lin = linear_split if SPLIT_VALUE_PROJ else linear_f32
+        half = getattr(value, "simpb_f16", None)   # the FPN left the same tokens in f16 (detector.FPN): two passes suffice
+        if SPLIT_VALUE_PROJ and half is not None and half.shape == value.shape:
+            value = half
         value = lin(value, self.value_proj.weight, self.value_proj.bias)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)

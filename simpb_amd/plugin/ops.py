@@ -375,8 +375,9 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_u
 def conv3x3_nhwc(x, weight, bias, relu=True, stride=1, tokens=None, variant=0):
     """relu?(conv3x3(x, weight, stride, padding=1) + bias) for a channels_last f16 tensor, one launch (csrc/conv3x3.hip).
     x [N, Cin, H, W]; weight f16 [Cout, Cin, 3, 3] (channels_last, i.e. [Cout][3][3][Cin] in memory); bias f16 [Cout].
-    tokens = (col_feats f32 [bs, cams * tokens_per_cam, Cout], tokens_per_cam, level_start): the result is written as
-    fp32 token rows of this level (feature_maps_format layout) instead of a map, and None is returned."""
+    tokens = (col_feats f32 [bs, cams * tokens_per_cam, Cout], tokens_per_cam, level_start[, col_f16]): the result is written
+    as fp32 token rows of this level (feature_maps_format layout) instead of a map (and, with col_f16, as the same rows in
+    f16), and None is returned."""
     _require_gpu(x, weight, bias)
     n, cin, h, w = x.shape
     cout = weight.shape[0]
@@ -387,17 +388,21 @@ def conv3x3_nhwc(x, weight, bias, relu=True, stride=1, tokens=None, variant=0):
     if not weight.is_contiguous(memory_format=torch.channels_last):
         weight = weight.contiguous(memory_format=torch.channels_last)
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    col16 = None
     if tokens is None:
         y = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float16, memory_format=torch.channels_last)
         col, per_cam, start = None, 0, 0
     else:
-        col, per_cam, start = tokens
+        col, per_cam, start = tokens[:3]
+        col16 = tokens[3] if len(tokens) > 3 else None
         y = None
+        if col16 is not None and (col16.dtype != torch.float16 or not col16.is_contiguous() or col16.shape != col.shape):
+            raise ValueError("tokens: the f16 buffer must match col_feats")
         if (col.dtype != torch.float32 or not col.is_contiguous() or col.shape[-1] != cout or col.numel() != n * per_cam * cout
                 or start < 0 or start + ho * wo > per_cam):
             raise ValueError("tokens: (contiguous f32 [bs, cams * tokens_per_cam, Cout] with bs * cams == N, tokens_per_cam, level_start)")
     status = _lib.lib().simpb_conv3x3_nhwc_f16(_ptr(y) if y is not None else None, _ptr(col) if col is not None else None,
-                                               per_cam, start, _ptr(x), _ptr(weight), _ptr(bias), n, h, w, cin, cout, stride,
+                                               _ptr(col16) if col16 is not None else None, per_cam, start, _ptr(x), _ptr(weight), _ptr(bias), n, h, w, cin, cout, stride,
                                                1 if relu else 0, variant, _stream())
     _lib.check(status, "simpb_conv3x3_nhwc_f16")
     return y
@@ -424,7 +429,8 @@ def topk_rows(scores, k):
 def linear_split(x, weight, bias=None):
     """F.linear(x, weight, bias) at fp32-grade accuracy on the FP16 matrix cores (csrc/linear_split.hip):
     both operands split into a leading and a 2^11-scaled trailing half-precision part, three products in
-    fp32 accumulators. |x|, |weight| must be below the half-precision range. x [..., K], weight [N, K]."""
+    fp32 accumulators. |x|, |weight| must be below the half-precision range. x [..., K] f32, or f16 (then its trailing part
+    is zero and two passes give the same result), weight [N, K]."""
     _require_gpu(x, weight)
     k = x.shape[-1]
     if weight.shape[1] != k or k % 32:
@@ -438,10 +444,17 @@ def linear_split(x, weight, bias=None):
             lo = ((w - hi.float()) * 2048.0).half()
         hit = (tag, hi.contiguous(), lo.contiguous())
         weight._simpb_split_lin = hit
-    x2 = x.contiguous().float().reshape(-1, k)
-    m, n = x2.shape[0], weight.shape[0]
+    m, n = x.numel() // k, weight.shape[0]
     y = torch.empty(m, n, device=x.device, dtype=torch.float32)
     b = bias.contiguous().float() if bias is not None else None
+    if x.dtype == torch.float16 and k % 64 == 0:
+        # x is half precision already (no trailing part): two passes (simpb_linear_f16in_split)
+        x2 = x.contiguous().reshape(-1, k)
+        if m:
+            _lib.check(_lib.lib().simpb_linear_f16in_split(_ptr(y), _ptr(x2), _ptr(hit[1]), _ptr(hit[2]), _ptr(b) if b is not None else None,
+                                                           m, n, k, _stream()), "simpb_linear_f16in_split")
+        return y.reshape(x.shape[:-1] + (n,))
+    x2 = x.contiguous().float().reshape(-1, k)
     if m:
         _lib.check(_lib.lib().simpb_linear_f16x3(_ptr(y), _ptr(x2), _ptr(hit[1]), _ptr(hit[2]), _ptr(b) if b is not None else None,
                                                  m, n, k, _stream()), "simpb_linear_f16x3")

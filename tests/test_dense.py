@@ -457,6 +457,28 @@ def test_linear_split_fp16_passes_reach_fp32_accuracy(m, scale):
 
 
 @gpu
+@pytest.mark.parametrize("m,n,k,scale", [(89760, 256, 256, 1.0), (1000, 256, 256, 1e-3), (77, 40, 192, 100.0), (130, 72, 64, 1.0)])
+def test_linear_split_with_half_precision_input(m, n, k, scale):
+    """simpb_linear_f16in_split (two passes, x already f16: the camera tokens of the fp16 backbone, simpb.py:63) against
+    float64 on the same f16 values, the 2e-5 bound of the exact fp32 kernel, and against the three-pass kernel on the
+    widened x (same terms: the trailing part of x is zero; only the summation order differs). Ragged M / N, 1 and 3
+    K chunks included."""
+    from simpb_amd.plugin.ops import linear_split
+    g = torch.Generator().manual_seed(m + n)
+    x = (torch.randn(m, k, generator=g) * scale).half()
+    w = torch.randn(n, k, generator=g) / 16
+    b = torch.randn(n, generator=g) * scale
+    want = x.double() @ w.double().t() + b.double()
+    got = linear_split(x.cuda(), w.cuda(), b.cuda()).cpu()
+    assert got.dtype == torch.float32 and got.shape == (m, n)
+    bound = 2e-5 * float(want.abs().max())
+    assert float((got.double() - want).abs().max()) <= bound
+    if k % 32 == 0:
+        three = linear_split(x.float().cuda(), w.cuda(), b.cuda()).cpu()
+        assert float((got - three).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+@gpu
 @pytest.mark.parametrize("cin,cout,h,w,stride,res,relu", [
     (64, 256, 64, 176, 1, True, True),      # layer1 conv3 + residual
     (256, 64, 64, 176, 1, False, True),     # layer1 conv1
@@ -525,16 +547,18 @@ def test_conv3x3_writes_tokens():
     shapes = [(16, 44), (8, 22), (4, 11), (2, 6)]
     per_cam = sum(h * w for h, w in shapes)
     col = torch.full((bs, cams * per_cam, c), float("nan"), device="cuda")
+    col16 = torch.full((bs, cams * per_cam, c), float("nan"), device="cuda", dtype=torch.float16)
     maps, start = [], 0
     for h, w in shapes:
         x = torch.randn(bs * cams, c, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
         wt = (torch.randn(c, c, 3, 3, generator=g) / 48).half().cuda().contiguous(memory_format=torch.channels_last)
         b = torch.randn(c, generator=g).half().cuda()
         maps.append(conv3x3_nhwc(x, wt, b, relu=False))
-        assert conv3x3_nhwc(x, wt, b, relu=False, tokens=(col, per_cam, start)) is None
+        assert conv3x3_nhwc(x, wt, b, relu=False, tokens=(col, per_cam, start, col16)) is None
         start += h * w
     want = feature_maps_format([m.float().reshape(bs, cams, c, *m.shape[2:]) for m in maps])[0]
     assert torch.equal(col, want)
+    assert torch.equal(col16.float(), want)      # the same rows without the widening (value_proj's input)
     with pytest.raises(ValueError):
         conv3x3_nhwc(x, wt, b, relu=False, tokens=(col, per_cam, per_cam - 1))   # level does not fit its block
 
