@@ -195,10 +195,12 @@ int simpb_bias_act_nhwc_f16(void* y, const void* bias, const void* residual, lon
  * BN-folded 3x3 convolution that produced x (bottleneck conv2 -> conv3) without a pass of its own; fp32
  * accumulate. stride 1 or 2; in_channels % 64 == 0, out_channels % 8 == 0; 16-byte aligned. These are conv1 / conv3 /
  * downsample of every ResNet bottleneck and the FPN lateral convolutions (mmdet ResNet + FPN of
- * projects/configs/simpb_nus_r50_img_704x256.py:79-99 after tools/fuse_conv_bn.py:10-48). */
+ * projects/configs/simpb_nus_r50_img_704x256.py:79-99 after tools/fuse_conv_bn.py:10-48). variant 0 = choose the kernel
+ * from the shape; 1 = the round-1 kernel (single LDS stage; the only one that takes input_bias); 2 / 3 = 128 x 64 / 128 x 128
+ * tiles of the staged pipeline of simpb_conv3x3_nhwc_f16 (same sums up to fp32 summation order). */
 int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const void* bias, const void* residual,
                            int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride, int relu,
-                           int residual_upsample2x, const void* input_bias, void* stream);
+                           int residual_upsample2x, const void* input_bias, int variant, void* stream);
 
 /* A whole BN-folded 3x3 convolution (padding 1) of the fp16 channels_last backbone in one launch, as an implicit GEMM:
  *   out[n, ho, wo, :] = relu?( sum_{dy,dx} x[n, ho*stride + dy - 1, wo*stride + dx - 1, :] . weight[:, dy, dx, :]^T + bias )
@@ -212,10 +214,10 @@ int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const voi
  *          layout, or NULL): the same rows without the widening, for simpb_linear_f16in_split (value_proj).
  * These are conv2 of every ResNet bottleneck and FPN.fpn_convs (mmdet ResNet + FPN of
  * projects/configs/simpb_nus_r50_img_704x256.py:79-99 after tools/fuse_conv_bn.py:10-48). stride 1 or 2;
- * in_channels % 64 == 0, out_channels % 8 == 0; 16-byte aligned. variant 0 = choose the tiling from the shape; 1-6 force one
+ * in_channels % 64 == 0, out_channels % 8 == 0; 16-byte aligned. variant 0 = choose the tiling from the shape; 1-8 force one
  * (pixels x channels per workgroup: 1 = 128 x 64 and 2 = 256 x 64 with the activations read straight into the MFMA layout;
- * 3 = 32 x 64 and 4 = 64 x 64 with K split over the workgroup's waves; 5 = 128 x 64 and 6 = 128 x 128 with both operands
- * staged through LDS) -- all give the same sums up to fp32 summation order. */
+ * 3 = 32 x 64 and 4 = 64 x 64 with K split over the workgroup's waves; 5 = 128 x 64, 6 = 128 x 128, 7 = 96 x 64 and
+ * 8 = 96 x 128 with both operands staged through LDS) -- all give the same sums up to fp32 summation order. */
 int simpb_conv3x3_nhwc_f16(void* y, float* tokens, void* tokens_f16, int tokens_per_cam, int level_start, const void* x,
                            const void* weight, const void* bias, int num_images, int in_h, int in_w, int in_channels,
                            int out_channels, int stride, int relu, int variant, void* stream);

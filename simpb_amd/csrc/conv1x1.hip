@@ -20,6 +20,10 @@
 #include "mfma_f16.h"
 
 extern "C" int simpb_check_launch(void);
+// csrc/conv3x3.hip: the same convolution through its staged pipeline (TAPS = 1)
+extern "C" int simpb_conv_pointwise_staged(void* y, const void* x, const void* weight, const void* bias, const void* residual,
+                                           int p_out, int in_h, int in_w, int ho, int wo, int in_channels, int out_channels,
+                                           int stride, int relu, int residual_upsample2x, int tiling, void* stream);
 
 namespace {
 
@@ -198,7 +202,8 @@ __global__ __launch_bounds__(kThreads) void conv1x1_f16_kernel(_Float16* __restr
 
 extern "C" int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight, const void* bias, const void* residual,
                                       int num_images, int in_h, int in_w, int in_channels, int out_channels, int stride,
-                                      int relu, int residual_upsample2x, const void* input_bias, void* stream) {
+                                      int relu, int residual_upsample2x, const void* input_bias, int variant, void* stream) {
+  if (variant < 0 || variant > 3 || (input_bias && variant > 1)) return SIMPB_EINVAL;
   if (!y || !x || !weight || !bias || num_images <= 0 || in_h <= 0 || in_w <= 0 || in_channels <= 0 || out_channels <= 0 ||
       (stride != 1 && stride != 2) || in_channels % BK != 0 || out_channels % 8 != 0)  // BK = 64
     return SIMPB_EINVAL;
@@ -210,6 +215,17 @@ extern "C" int simpb_conv1x1_nhwc_f16(void* y, const void* x, const void* weight
   const long long p_out = (long long)num_images * ho * wo;
   if (p_out > (1ll << 30)) return SIMPB_EINVAL;
   (void)hipGetLastError();
+  if (variant == 0) {
+    // measured (tools/bench_conv1x1.py): the staged pipeline of csrc/conv3x3.hip (XCD-ordered tiles, double-buffered
+    // stage, one barrier per chunk) wins where the K loop is long (8 chunks and more), this file's kernel on the short ones;
+    // the input-side epilogue exists only here
+    variant = (input_bias || in_channels < 512) ? 1 : 2;
+  }
+  if (variant > 1) {
+    if ((long long)num_images * in_h * in_w * in_channels > (1ll << 31) - 1) return SIMPB_EINVAL;
+    return simpb_conv_pointwise_staged(y, x, weight, bias, residual, (int)p_out, in_h, in_w, ho, wo, in_channels, out_channels,
+                                       stride, relu, residual_upsample2x, variant - 2, stream);
+  }
   dim3 grid((unsigned)((p_out + BM - 1) / BM), (out_channels + BN - 1) / BN);
   if (grid.y > 65535) return SIMPB_EINVAL;
   hipLaunchKernelGGL(conv1x1_f16_kernel, grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream),

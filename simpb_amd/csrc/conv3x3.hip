@@ -48,6 +48,8 @@ struct ConvArgs {
   float* tok;             // f32 token buffer or NULL (ops/__init__.py:63-92 layout: [bs, cams * tokens_per_cam, Cout])
   _Float16* tok16;        // the same rows in f16 (for value_proj's two-pass product) or NULL
   const _Float16 *x, *w, *bias;
+  const _Float16* residual;   // f16 like y (or half-size with res_up: read with nearest 2x upsampling), or NULL
+  int res_up;
   int P_out, Cin, Cout, relu, stride, Ho, Wo, H, W;
   int tokens_per_cam, level_start;
   int gx, gy, per_xcd;    // tile grid and tiles per XCD range
@@ -57,7 +59,7 @@ template <int S>
 using IC = std::integral_constant<int, S>;
 
 // one 16-byte piece of an output row: bias, ReLU, one rounding to fp16; to the f16 map or, widened, to the token buffer
-__device__ __forceinline__ void emit_piece(const ConvArgs& a, int c0, int p, int c8, const float (&v)[8]) {
+__device__ __forceinline__ void emit_piece(const ConvArgs& a, int c0, bool full, int p, int c8, const float (&v)[8]) {
   if (p >= a.P_out) return;
   size_t trow = 0;
   if (a.tok) {   // the FPN's output convolution writes the decoder's token row itself: fp32 values of the fp16 result
@@ -65,12 +67,25 @@ __device__ __forceinline__ void emit_piece(const ConvArgs& a, int c0, int p, int
     const int n = p / hw, pix = p - n * hw;
     trow = ((size_t)n * a.tokens_per_cam + a.level_start + pix) * a.Cout;
   }
-  if (c0 + BN <= a.Cout) {
+  size_t rrow = 0;
+  if (a.residual) {
+    int rp = p;
+    if (a.res_up) {   // F.interpolate(mode="nearest") of an exact 2x: source = floor(dst / 2) (the FPN top-down path)
+      const int hw = a.Ho * a.Wo;
+      const int n = p / hw, rem = p - n * hw;
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      rp = (n * (a.Ho >> 1) + (ho >> 1)) * (a.Wo >> 1) + (wo >> 1);
+    }
+    rrow = (size_t)rp * a.Cout;
+  }
+  if (full) {
     const h16x8 bv = *reinterpret_cast<const h16x8*>(a.bias + c0 + c8);
+    h16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.residual) rv = *reinterpret_cast<const h16x8*>(a.residual + rrow + c0 + c8);
     h16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float t = v[e] + (float)bv[e];
+      const float t = v[e] + (float)bv[e] + (float)rv[e];
       o[e] = (_Float16)(a.relu ? fmaxf(t, 0.f) : t);
     }
     if (a.tok) {
@@ -86,7 +101,8 @@ __device__ __forceinline__ void emit_piece(const ConvArgs& a, int c0, int p, int
     for (int e = 0; e < 8; ++e) {
       const int c = c0 + c8 + e;
       if (c < a.Cout) {
-        const float t = v[e] + (float)a.bias[c];
+        float t = v[e] + (float)a.bias[c];
+        if (a.residual) t += (float)a.residual[rrow + c];
         const _Float16 o = (_Float16)(a.relu ? fmaxf(t, 0.f) : t);
         if (a.tok) {
           a.tok[trow + c] = (float)o;
@@ -291,7 +307,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const ConvArgs
 
   // epilogue, one A fragment at a time: accumulators -> LDS (C/D layout: column = lane & 31,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)), then 16-byte pieces of full rows: bias, ReLU, one rounding to fp16
-  auto emit = [&](int p, int c8, const float (&v)[8]) __attribute__((always_inline)) { emit_piece(a, c0, p, c8, v); };
+  const bool full = c0 + BN <= a.Cout;
+  auto emit = [&](int p, int c8, const float (&v)[8]) __attribute__((always_inline)) { emit_piece(a, c0, full, p, c8, v); };
   float* mine = s_c + wave * 32 * LDC;
 #pragma unroll
   for (int f = 0; f < AF; ++f) {
@@ -342,16 +359,18 @@ void launch(ConvArgs& a, hipStream_t stream) {
 // 64 x 176 maps with the matrix cores half idle. Here 8 consecutive lanes load the 8 pieces of one pixel row (a
 // wave-instruction = 8 whole lines), the chunk goes through a double-buffered LDS stage (one barrier per chunk, three register
 // sets: loads run two chunks ahead), and fragments are read back with ds_read_b128 (256 B/clk per CU on gfx950, conflict-free
-// at a 144-byte row pitch). BMt x BNt output tile, waves WGM x (4 / WGM), each wave (BMt / WGM) x 64.
-template <int BMt, int BNt, int WGM>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_staged_kernel(const ConvArgs a) {
-  constexpr int WGN = 4 / WGM;
+// at a 144-byte row pitch). BMt x BNt output tile, WGM x WGN waves, each (BMt / WGM) x (BNt / WGN). The tile is chosen per shape so
+// that the grid fills whole rounds of the chip: 67 584 pixels are 528 tiles of 128 (two per CU and sixteen left over) but 704 of 96.
+template <int BMt, int BNt, int WGM, int WGN, int TAPS>
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 3 ? 3 : 2) void conv_staged_kernel(const ConvArgs a) {
+  constexpr int NT = 64 * WGM * WGN;
   constexpr int AF = BMt / WGM / 32, NF = BNt / WGN / 32;
-  static_assert(NF == 2, "a wave owns 64 output channels");
-  constexpr int NA = BMt / 32, NB = BNt / 32;       // staged pieces per thread and chunk
+  static_assert(AF * WGM * 32 == BMt && NF * WGN * 32 == BNt && NF <= 2, "tile = waves x 32-row / 32-column fragments");
+  constexpr int NA = (BMt * 8 + NT - 1) / NT, NB = (BNt * 8 + NT - 1) / NT;   // staged 16-byte pieces per thread and chunk
   constexpr int kRows = BMt + BNt;
-  constexpr int kStage = 2 * kRows * LDH * 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kStage > kTileBytes ? kStage : kTileBytes];
+  constexpr int LDW = 32 * NF + 1;                                             // floats per row of a wave's epilogue tile
+  constexpr int kStage = 2 * kRows * LDH * 2, kTile = WGM * WGN * 32 * LDW * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kStage > kTile ? kStage : kTile];
   _Float16* s_ab = reinterpret_cast<_Float16*>(smem);
   float* s_c = reinterpret_cast<float*>(smem);
 
@@ -364,29 +383,29 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_staged_kernel(const ConvA
   const int wm = wave / WGN, wn = wave - wm * WGN;
   const int p0 = tx * BMt, c0 = ty * BNt;
   const int Cin = a.Cin, W = a.W, H = a.H;
-  const int per_tap = Cin / BK, nchunks = 9 * per_tap;
-  const size_t K = (size_t)9 * Cin;
+  const int per_tap = Cin / BK, nchunks = TAPS * per_tap;
+  const size_t K = (size_t)TAPS * Cin;
   const _Float16* __restrict__ wgt = a.w;
 
-  const int sr = tid >> 3, sc = (tid & 7) * 8;
+  // piece i of this thread: index tid + NT * i -> (row, 8-half column) of the A or B part of the stage
+  const int sc = (tid & 7) * 8;
   const _Float16* actr[NA];   // centre of this thread's staged pixel rows (+ its piece)
-  unsigned amask = 0;         // 9 bits per row: taps inside the image
+  unsigned amask = 0;         // 6 bits per row: which of the 3 input rows / 3 input columns around it are inside the image
+  static_assert(NA <= 5, "6 mask bits per staged row in one register");
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int p = min(p0 + sr + 32 * i, a.P_out - 1);
+    const int p = min(p0 + ((tid + NT * i) >> 3), a.P_out - 1);
     const int hw = a.Ho * a.Wo;
     const int n = p / hw, rem = p - n * hw;
     const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
     const int hc = ho * a.stride, wc = wo * a.stride;
     actr[i] = a.x + ((size_t)(n * H + hc) * W + wc) * Cin + sc;
-    // rows of one thread are 32 pixels apart: their masks differ, but each is 3 row bits x 3 column bits
-    unsigned rows = (hc > 0 ? 1u : 0u) | 2u | (hc + 1 < H ? 4u : 0u), cols = (wc > 0 ? 1u : 0u) | 2u | (wc + 1 < W ? 4u : 0u);
-    if constexpr (NA <= 5) amask |= (rows | (cols << 3)) << (6 * i);
+    const unsigned rows = (hc > 0 ? 1u : 0u) | 2u | (hc + 1 < H ? 4u : 0u), cols = (wc > 0 ? 1u : 0u) | 2u | (wc + 1 < W ? 4u : 0u);
+    amask |= (rows | (cols << 3)) << (6 * i);
   }
-  static_assert(NA <= 5, "6 mask bits per staged row in one register");
   size_t brow[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) brow[i] = (size_t)min(c0 + sr + 32 * i, a.Cout - 1) * K + sc;
+  for (int i = 0; i < NB; ++i) brow[i] = (size_t)min(c0 + ((tid + NT * i) >> 3), a.Cout - 1) * K + sc;
 
   h16x8 ra[3][NA], rb[3][NB];
   unsigned alive[3];
@@ -394,30 +413,45 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_staged_kernel(const ConvA
   auto fetch = [&](auto set_c, int chunk) __attribute__((always_inline)) {
     constexpr int s = decltype(set_c)::value;
     const int c = min(chunk, nchunks - 1);
-    const int tap = c / per_tap, k0 = (c - tap * per_tap) * BK;
-    const int dy = tap / 3, dx = tap - dy * 3;
-    const int toff = ((dy - 1) * W + (dx - 1)) * Cin;
-    unsigned m = 0;
+    if constexpr (TAPS == 1) {   // a 1x1 convolution: the centre pixel only, always inside the image
+      const int k0 = c * BK;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const bool in = ((amask >> (6 * i + dy)) & (amask >> (6 * i + 3 + dx)) & 1u) != 0;
-      m |= (in ? 1u : 0u) << i;
-      ra[s][i] = *reinterpret_cast<const h16x8*>(actr[i] + (in ? toff : 0) + k0);
+      for (int i = 0; i < NA; ++i) ra[s][i] = *reinterpret_cast<const h16x8*>(actr[i] + k0);
+      alive[s] = ~0u;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb[s][i] = *reinterpret_cast<const h16x8*>(wgt + brow[i] + k0);
+    } else {
+      const int tap = c / per_tap, k0 = (c - tap * per_tap) * BK;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const int toff = ((dy - 1) * W + (dx - 1)) * Cin;
+      unsigned m = 0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const bool in = ((amask >> (6 * i + dy)) & (amask >> (6 * i + 3 + dx)) & 1u) != 0;
+        m |= (in ? 1u : 0u) << i;
+        ra[s][i] = *reinterpret_cast<const h16x8*>(actr[i] + (in ? toff : 0) + k0);
+      }
+      alive[s] = m;
+      const size_t koff = (size_t)tap * Cin + k0;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb[s][i] = *reinterpret_cast<const h16x8*>(wgt + brow[i] + koff);
     }
-    alive[s] = m;
-    const size_t koff = (size_t)tap * Cin + k0;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rb[s][i] = *reinterpret_cast<const h16x8*>(wgt + brow[i] + koff);
   };
   auto stash = [&](auto set_c, int buf) __attribute__((always_inline)) {
     constexpr int s = decltype(set_c)::value;
     const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     _Float16* base = s_ab + buf * kRows * LDH;
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      *reinterpret_cast<h16x8*>(&base[(sr + 32 * i) * LDH + sc]) = ((alive[s] >> i) & 1u) ? ra[s][i] : zero;
+    for (int i = 0; i < NA; ++i) {
+      const int idx = tid + NT * i;
+      if ((BMt * 8) % NT == 0 || idx < BMt * 8)
+        *reinterpret_cast<h16x8*>(&base[(idx >> 3) * LDH + sc]) = ((alive[s] >> i) & 1u) ? ra[s][i] : zero;
+    }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<h16x8*>(&base[(BMt + sr + 32 * i) * LDH + sc]) = rb[s][i];
+    for (int i = 0; i < NB; ++i) {
+      const int idx = tid + NT * i;
+      if ((BNt * 8) % NT == 0 || idx < BNt * 8) *reinterpret_cast<h16x8*>(&base[(BMt + (idx >> 3)) * LDH + sc]) = rb[s][i];
+    }
   };
 
   f32x16 acc[AF][NF];
@@ -460,39 +494,45 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_staged_kernel(const ConvA
     multiply(c & 1);
     __syncthreads();
   };
-  for (int c = 0; c < nchunks; c += 3) {   // nchunks = 9 * per_tap: a multiple of 3
+  for (int c = 0; c < nchunks; c += 3) {   // 9 * per_tap is a multiple of 3; a 1x1 convolution has any count
     step(IC<0>{}, IC<1>{}, c);
-    step(IC<1>{}, IC<2>{}, c + 1);
-    step(IC<2>{}, IC<0>{}, c + 2);
+    if (TAPS == 9 || c + 1 < nchunks) step(IC<1>{}, IC<2>{}, c + 1);
+    if (TAPS == 9 || c + 2 < nchunks) step(IC<2>{}, IC<0>{}, c + 2);
   }
 
-  float* mine = s_c + wave * 32 * LDC;
+  // epilogue, one A fragment at a time through the wave's own 32 x (32 * NF) fp32 tile: 16-byte pieces of output rows
+  float* mine = s_c + wave * 32 * LDW;
+  const int cw = c0 + wn * NF * 32;
+  const bool full = cw + 32 * NF <= a.Cout;
 #pragma unroll
   for (int f = 0; f < AF; ++f) {
     if (f) __syncthreads();
 #pragma unroll
     for (int n = 0; n < NF; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * kb) * LDC + n * 32 + r32] = acc[f][n][r];
+      for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * kb) * LDW + n * 32 + r32] = acc[f][n][r];
     __syncthreads();
+    constexpr int PR = 4 * NF;            // pieces per row
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int r = (lane >> 3) + 8 * pass, c8 = (lane & 7) * 8;
+    for (int pass = 0; pass < 32 * PR / 64; ++pass) {
+      const int idx = lane + 64 * pass;
+      const int r = idx / PR, c8 = (idx % PR) * 8;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = mine[r * LDC + c8 + e];
-      emit_piece(a, c0 + wn * 64, p0 + (wm * AF + f) * 32 + r, c8, v);
+      for (int e = 0; e < 8; ++e) v[e] = mine[r * LDW + c8 + e];
+      emit_piece(a, cw, full, p0 + (wm * AF + f) * 32 + r, c8, v);
     }
   }
 }
 
-template <int BMt, int BNt, int WGM>
+template <int BMt, int BNt, int WGM, int WGN, int TAPS>
 void launch_staged(ConvArgs& a, hipStream_t stream) {
   a.gx = (a.P_out + BMt - 1) / BMt;
   a.gy = (a.Cout + BNt - 1) / BNt;
   const long long total = (long long)a.gx * a.gy;
   a.per_xcd = (int)((total + 7) / 8);
-  hipLaunchKernelGGL((conv3x3_staged_kernel<BMt, BNt, WGM>), dim3((unsigned)(a.per_xcd * 8)), dim3(kThreads), 0, stream, a);
+  hipLaunchKernelGGL((conv_staged_kernel<BMt, BNt, WGM, WGN, TAPS>), dim3((unsigned)(a.per_xcd * 8)), dim3(64 * WGM * WGN), 0,
+                     stream, a);
 }
 
 }  // namespace
@@ -502,7 +542,7 @@ extern "C" int simpb_conv3x3_nhwc_f16(void* y, float* tokens, void* tokens_f16, 
                                       int in_channels, int out_channels, int stride, int relu, int variant, void* stream) {
   if ((!y && !tokens) || (y && tokens) || (tokens_f16 && !tokens) || (reinterpret_cast<size_t>(tokens_f16) & 15) || !x || !weight || !bias || num_images <= 0 || in_h <= 0 || in_w <= 0 ||
       in_channels <= 0 || out_channels <= 0 || (stride != 1 && stride != 2) || in_channels % BK != 0 || out_channels % 8 != 0 ||
-      variant < 0 || variant > 6)
+      variant < 0 || variant > 8)
     return SIMPB_EINVAL;
   if ((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(tokens) | reinterpret_cast<size_t>(x) |
        reinterpret_cast<size_t>(weight) | reinterpret_cast<size_t>(bias)) & 15)
@@ -514,15 +554,16 @@ extern "C" int simpb_conv3x3_nhwc_f16(void* y, float* tokens, void* tokens_f16, 
   if (tokens && (tokens_per_cam < ho * wo || level_start < 0 || level_start + ho * wo > tokens_per_cam)) return SIMPB_EINVAL;
   (void)hipGetLastError();
   ConvArgs a{static_cast<_Float16*>(y), tokens, static_cast<_Float16*>(tokens_f16), static_cast<const _Float16*>(x), static_cast<const _Float16*>(weight),
-             static_cast<const _Float16*>(bias), (int)p_out, in_channels, out_channels, relu, stride, ho, wo, in_h, in_w,
+             static_cast<const _Float16*>(bias), nullptr, 0, (int)p_out, in_channels, out_channels, relu, stride, ho, wo, in_h, in_w,
              tokens_per_cam, level_start, 0, 0, 0};
   const long long ny = (out_channels + BN - 1) / BN;
   if (variant == 0) {
-    // measured on the ResNet50 / FPN shapes at 6 x 256 x 704 (tools/bench_conv3x3.py): the LDS-staged tilings while they
-    // yield at least one workgroup per CU, then the direct ones, K split inside the workgroup for the smallest maps
-    const long long t128 = (p_out + 127) / 128, t64 = (p_out + 63) / 64;
-    if (t128 * ((out_channels + 127) / 128) >= 256) variant = 6;
-    else if (t128 * ny >= 256) variant = 5;
+    // measured on the ResNet50 / FPN shapes at 6 x 256 x 704 (tools/bench_conv3x3.py): the LDS-staged 96-row tilings while
+    // they fill the chip (96 divides the pixel counts of a 6-camera rig and leaves no nearly empty last round of
+    // workgroups), then the direct ones, K split inside the workgroup for the smallest maps
+    const long long t96 = (p_out + 95) / 96, t128 = (p_out + 127) / 128, t64 = (p_out + 63) / 64;
+    if (out_channels >= 128 && t96 * ((out_channels + 127) / 128) >= 160) variant = 8;
+    else if (t96 * ny >= 256) variant = 7;
     else if (t128 * ny >= 128) variant = 1;
     else if (t64 * ny >= 128) variant = 4;
     else variant = 3;
@@ -533,8 +574,24 @@ extern "C" int simpb_conv3x3_nhwc_f16(void* y, float* tokens, void* tokens_f16, 
     case 2: launch<2, false>(a, s); break;   // 256 x 64
     case 3: launch<1, true>(a, s); break;    // 32 x 64, K split over the waves
     case 4: launch<2, true>(a, s); break;    // 64 x 64, K split over the waves
-    case 5: launch_staged<128, 64, 4>(a, s); break;    // 128 x 64, operands staged through LDS
-    default: launch_staged<128, 128, 2>(a, s); break;  // 128 x 128
+    case 5: launch_staged<128, 64, 4, 1, 9>(a, s); break;    // 128 x 64, operands staged through LDS
+    case 6: launch_staged<128, 128, 2, 2, 9>(a, s); break;  // 128 x 128
+    case 7: launch_staged<96, 64, 3, 1, 9>(a, s); break;     // 96 x 64, three waves: 704 workgroups for 67 584 pixels
+    default: launch_staged<96, 128, 1, 4, 9>(a, s); break;   // 96 x 128, waves side by side along the channels
   }
+  return simpb_check_launch();
+}
+
+// 1x1 convolutions through the same staged pipeline (TAPS = 1): csrc/conv1x1.hip validates and forwards here.
+// tiling 0: 128 x 64 per workgroup, 1: 128 x 128.
+extern "C" int simpb_conv_pointwise_staged(void* y, const void* x, const void* weight, const void* bias, const void* residual,
+                                           int p_out, int in_h, int in_w, int ho, int wo, int in_channels, int out_channels,
+                                           int stride, int relu, int residual_upsample2x, int tiling, void* stream) {
+  ConvArgs a{static_cast<_Float16*>(y), nullptr, nullptr, static_cast<const _Float16*>(x), static_cast<const _Float16*>(weight),
+             static_cast<const _Float16*>(bias), static_cast<const _Float16*>(residual), residual_upsample2x ? 1 : 0,
+             p_out, in_channels, out_channels, relu, stride, ho, wo, in_h, in_w, 0, 0, 0, 0, 0};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (tiling == 0) launch_staged<128, 64, 4, 1, 1>(a, s);
+  else launch_staged<128, 128, 2, 2, 1>(a, s);
   return simpb_check_launch();
 }

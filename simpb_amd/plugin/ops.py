@@ -340,7 +340,7 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
-def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_upsample2x=False, input_bias=None):
+def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_upsample2x=False, input_bias=None, variant=0):
     """relu?(conv1x1(x, weight, stride) + bias + residual?) for a channels_last f16 tensor, one launch
     (csrc/conv1x1.hip). x [N, Cin, H, W]; weight [Cout, Cin, 1, 1] f16; bias f16 [Cout]. With residual_upsample2x the
     residual is [N, Cout, H/2, W/2] and is read with nearest-neighbour 2x upsampling (the FPN top-down sum). With
@@ -367,7 +367,7 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_u
     status = _lib.lib().simpb_conv1x1_nhwc_f16(_ptr(y), _ptr(x), _ptr(w2), _ptr(bias), _ptr(residual) if residual is not None else None,
                                                n, h, w, cin, cout, stride, 1 if relu else 0,
                                                1 if residual_upsample2x else 0,
-                                               _ptr(input_bias) if input_bias is not None else None, _stream())
+                                               _ptr(input_bias) if input_bias is not None else None, variant, _stream())
     _lib.check(status, "simpb_conv1x1_nhwc_f16")
     return y
 

@@ -486,7 +486,8 @@ def test_linear_split_with_half_precision_input(m, n, k, scale):
     (2048, 512, 8, 22, 1, False, True),     # layer4 conv1, small map
     (192, 40, 5, 7, 2, True, True),         # ragged pixels / channels, odd sizes with stride 2, 3 K chunks
 ])
-def test_conv1x1_kernel_vs_conv2d(cin, cout, h, w, stride, res, relu):
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_conv1x1_kernel_vs_conv2d(cin, cout, h, w, stride, res, relu, variant):
     """csrc/conv1x1.hip against F.conv2d + bias (+ residual) (+ ReLU) evaluated in fp32 on the same fp16 values:
     the kernel accumulates in fp32 and rounds once, so it must sit within one fp16 rounding of that reference."""
     from simpb_amd.plugin.ops import conv1x1_nhwc
@@ -501,14 +502,14 @@ def test_conv1x1_kernel_vs_conv2d(cin, cout, h, w, stride, res, relu):
         want = want + r.float()
     if relu:
         want = want.relu()
-    got = conv1x1_nhwc(x, wt, b, r, relu, stride)
+    got = conv1x1_nhwc(x, wt, b, r, relu, stride, variant=variant)
     assert got.shape == want.shape and got.dtype == torch.float16 and got.is_contiguous(memory_format=torch.channels_last)
     err = (got.float() - want).abs()
     assert float((err - 1e-3 * want.abs()).max()) <= 2e-3   # fp16 output rounding: 2^-11 relative + small absolute
 
 
 @gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("cin,cout,h,w,stride,relu", [
     (64, 64, 64, 176, 1, True),       # layer1 conv2
     (128, 128, 64, 176, 2, True),     # layer2.0 conv2, stride 2
@@ -564,8 +565,9 @@ def test_conv3x3_writes_tokens():
 
 
 @gpu
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("cin,cout,h,w", [(512, 256, 32, 88), (256, 256, 64, 176), (1024, 256, 16, 44), (192, 40, 6, 10)])
-def test_conv1x1_with_upsampled_residual(cin, cout, h, w):
+def test_conv1x1_with_upsampled_residual(cin, cout, h, w, variant):
     """The FPN top-down sum lateral[i-1] = conv1x1(c[i-1]) + interpolate(lateral[i], nearest) (mmdet FPN.forward) with
     the 2x nearest read done inside the launch, against the materialised F.interpolate + conv1x1 residual route (same
     kernel, same arithmetic: bit-exact) and against fp32 F.conv2d."""
@@ -576,8 +578,8 @@ def test_conv1x1_with_upsampled_residual(cin, cout, h, w):
     b = torch.randn(cout, generator=g).half().cuda()
     coarse = torch.randn(3, cout, h // 2, w // 2, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
     up = F.interpolate(coarse, size=(h, w), mode="nearest").contiguous(memory_format=torch.channels_last)
-    want = conv1x1_nhwc(x, wt, b, up, relu=False)
-    got = conv1x1_nhwc(x, wt, b, coarse, relu=False, residual_upsample2x=True)
+    want = conv1x1_nhwc(x, wt, b, up, relu=False, variant=variant)
+    got = conv1x1_nhwc(x, wt, b, coarse, relu=False, residual_upsample2x=True, variant=variant)
     assert torch.equal(got, want)
     ref = F.conv2d(x.float(), wt.float(), b.float()) + up.float()
     assert float((got.float() - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))

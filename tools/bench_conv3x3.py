@@ -46,7 +46,7 @@ for name, cin, cout, h, w, stride in SHAPES:
     tv = timeit(vendor)
     line = f"{name:15s} {cin:3d}->{cout:3d} {h:3d}x{w:3d} s{stride} {gflop:5.2f} GF  vendor+bias_act {tv:6.1f} us |"
     best = 1e9
-    for v in (0, 1, 2, 3, 4, 5, 6):
+    for v in (0, 1, 2, 3, 4, 5, 6, 7, 8):
         fn = lambda i: conv3x3_nhwc(xs[i & 3], wt, b, True, stride, variant=v)  # noqa: E731
         err = float((fn(0).float() - ref).abs().max())
         t = timeit(fn)
