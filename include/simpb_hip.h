@@ -420,6 +420,16 @@ int simpb_alloc_scatter(float* ref_pts2d, float* ref_depth2d, int* q2a, int* is_
                         const float* sel_xy, const float* depth, int batch_size, int num_anchors, int num_cams,
                         int num_query, float img_w, float img_h, void* stream);
 
+/* Steps 1-3 with a fixed capacity in ONE launch (a replayed frame pays ~4.7 us of dispatch per kernel, and these are
+ * five kernels of well under a microsecond of work, three times per frame): every output of simpb_alloc_project,
+ * simpb_alloc_compact, simpb_alloc_group_start (capacity = num_query) and simpb_alloc_scatter, same arithmetic, same
+ * tables. num_cams <= 64. */
+int simpb_alloc_static(unsigned char* flag, float* sel_xy, float* depth, int* count, int* order, int* group_start,
+                       int* overflow, float* ref_pts2d, float* ref_depth2d, int* q2a, int* is_center, int* a2q,
+                       int* query_cam, const float* anchor, const float* projection_mat, int batch_size, int num_anchors,
+                       int num_cams, int capacity, float img_w, float img_h, float limit_w, float limit_l, float limit_h,
+                       void* stream);
+
 /* out[b, s, :] = src[b, q2a[b, s], :], zeros where q2a < 0: replaces
  * torch.matmul(ref_trans_matrix, instance_feature) (models/simpb_head.py:438). channels % 4 == 0. */
 int simpb_gather_rows(float* out, const float* src, const int* q2a, int batch_size, int num_anchors,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "simpb_alloc_compact": ([_P] * 3 + [_I] * 3 + [_P], _I),
     "simpb_alloc_group_start": ([_P] * 3 + [_I] * 3 + [_P], _I),
     "simpb_alloc_scatter": ([_P] * 12 + [_I] * 4 + [_F] * 2 + [_P], _I),
+    "simpb_alloc_static": ([_P] * 15 + [_I] * 4 + [_F] * 5 + [_P], _I),
     "simpb_gather_rows": ([_P] * 3 + [_I] * 4 + [_P], _I),
     "simpb_aggregate_2d_to_3d": ([_P] * 8 + [_I] * 5 + [_P], _I),
 }

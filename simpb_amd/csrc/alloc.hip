@@ -203,6 +203,154 @@ __global__ void aggregate_kernel(float* __restrict__ out_q, float* __restrict__ 
   }
 }
 
+// ---- the static-capacity allocation of one frame layer in ONE launch ---------------------------------------------------
+// In a replayed frame every kernel costs ~4.7 us of dispatch whatever it does, and steps 1-3 above are five launches of a few
+// hundred nanoseconds of work each (x 3 allocation layers per frame). With a fixed capacity nothing goes back to the host
+// between them, so one workgroup of 1 024 threads walks the steps itself, a workgroup barrier (+ device-scope fence: the
+// steps hand their results over through global memory) between two steps. Same arithmetic per element, same tables.
+__global__ __launch_bounds__(1024) void alloc_static_kernel(
+    unsigned char* __restrict__ flag, float* __restrict__ sel_xy, float* __restrict__ depth, int* __restrict__ count,
+    int* __restrict__ order, int* __restrict__ group_start, int* __restrict__ overflow, float* __restrict__ ref_pts2d,
+    float* __restrict__ ref_depth2d, int* __restrict__ q2a, int* __restrict__ is_center, int* __restrict__ a2q,
+    int* __restrict__ query_cam, const float* __restrict__ anchor, const float* __restrict__ proj, int bs, int A, int cams,
+    int N2, float img_w, float img_h, float lim_w, float lim_l, float lim_h) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto handover = [&]() {
+    __threadfence();
+    __syncthreads();
+  };
+  // step 1 (alloc_project_kernel) + the -1 fill of a2q
+  for (int idx = tid; idx < bs * A * cams; idx += 1024) {
+    const int cam = idx % cams;
+    const int a = (idx / cams) % A;
+    const int b = idx / (cams * A);
+    const float* an = anchor + ((size_t)b * A + a) * 11;
+    const float* P = proj + ((size_t)b * cams + cam) * 16;
+    const float cx = an[0], cy = an[1], cz = an[2];
+    const float sw = fminf(expf(an[3]), lim_w), sl = fminf(expf(an[4]), lim_l), sh = fminf(expf(an[5]), lim_h);
+    const float sn = an[6], cs = an[7];
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    bool corner_valid = false;
+    float ctr_x = 0.f, ctr_y = 0.f, ctr_d = 0.f;
+    for (int k = 0; k < 9; ++k) {
+      float px, py, pz;
+      if (k < 8) {
+        const float ox = (((k >> 2) & 1) - 0.5f) * sw, oy = (((k >> 1) & 1) - 0.5f) * sl, oz = ((k & 1) - 0.5f) * sh;
+        px = cs * ox - sn * oy + cx;
+        py = sn * ox + cs * oy + cy;
+        pz = oz + cz;
+      } else {
+        px = cx; py = cy; pz = cz;
+      }
+      const float u = P[0] * px + P[1] * py + P[2] * pz + P[3];
+      const float v = P[4] * px + P[5] * py + P[6] * pz + P[7];
+      const float d = P[8] * px + P[9] * py + P[10] * pz + P[11];
+      const float dc = fmaxf(d, 1e-5f);
+      const float x = u / dc, y = v / dc;
+      const bool inside = 0.f < x && x < img_w && 0.f < y && y < img_h;
+      if (k < 8) {
+        corner_valid = corner_valid || (d > 0.f && inside);
+        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+        ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+      } else {
+        ctr_x = x; ctr_y = y; ctr_d = d;
+      }
+    }
+    const bool center_valid = 0.f < ctr_x && ctr_x < img_w && 0.f < ctr_y && ctr_y < img_h;
+    float sx = (fminf(fmaxf(xmin, 0.f), img_w) + fminf(fmaxf(xmax, 0.f), img_w)) / 2.f;
+    float sy = (fminf(fmaxf(ymin, 0.f), img_h) + fminf(fmaxf(ymax, 0.f), img_h)) / 2.f;
+    if (center_valid) { sx = ctr_x; sy = ctr_y; }
+    int fl = center_valid ? 2 : (corner_valid ? 1 : 0);
+    simpb::pin(sx); simpb::pin(sy); simpb::pin(ctr_d); simpb::pin(fl);
+    simpb::loads_retired();
+    const size_t o = ((size_t)b * cams + cam) * A + a;
+    flag[o] = (unsigned char)fl;
+    sel_xy[2 * o] = sx;
+    sel_xy[2 * o + 1] = sy;
+    depth[o] = ctr_d;
+    a2q[idx] = -1;
+    simpb::loads_retired();
+  }
+  handover();
+  // step 2 (alloc_compact_kernel), one (batch, camera) list after the other
+  for (int bc = 0; bc < bs * cams; ++bc) {
+    const unsigned char* f = flag + (size_t)bc * A;
+    int* ord = order + (size_t)bc * A;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int a0 = 0; a0 < A; a0 += 1024) {
+      const int a = a0 + tid;
+      bool on = false;
+      if (a < A) on = f[a] != 0;
+      simpb::loads_retired();
+      const unsigned long long m = __ballot(on);
+      if (lane == 0) s_wave[wave] = __popcll(m);
+      __syncthreads();
+      int off = s_base;
+      for (int w = 0; w < wave; ++w) off += s_wave[w];
+      if (on) ord[off + __popcll(m & ((1ull << lane) - 1ull))] = a;
+      __syncthreads();
+      if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += s_wave[w];
+        s_base += t;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) count[bc] = s_base;
+  }
+  handover();
+  // group table (alloc_group_start_kernel)
+  if (tid == 0) {
+    int acc = 0;
+    bool over = false;
+    int gs[64];
+    for (int c = 0; c < cams; ++c) {
+      int m = 0;
+      for (int b = 0; b < bs; ++b) m = max(m, count[b * cams + c]);
+      acc += m;
+      if (acc > N2) { over = true; acc = N2; }
+      gs[c] = acc;
+    }
+    simpb::loads_retired();
+    group_start[0] = 0;
+    for (int c = 0; c < cams; ++c) group_start[c + 1] = gs[c];
+    overflow[0] = over ? 1 : 0;
+  }
+  handover();
+  // step 3 (alloc_scatter_kernel)
+  for (int idx = tid; idx < bs * N2; idx += 1024) {
+    const int slot = idx % N2, b = idx / N2;
+    int cam = 0;
+    while (cam + 1 < cams && slot >= group_start[cam + 1]) ++cam;
+    const int rank = slot - group_start[cam];
+    const bool in_set = slot < group_start[cams];
+    const int bc = b * cams + cam;
+    float x = 0.f, y = 0.f, d = 0.f;
+    int a = -1, ctr = 0;
+    if (in_set && rank < count[bc]) {
+      a = order[(size_t)bc * A + rank];
+      const size_t o = (size_t)bc * A + a;
+      x = sel_xy[2 * o] / img_w;
+      y = sel_xy[2 * o + 1] / img_h;
+      d = fabsf(depth[o]);
+      ctr = flag[o] == 2;
+    }
+    simpb::pin(x); simpb::pin(y); simpb::pin(d); simpb::pin(a); simpb::pin(ctr);
+    simpb::loads_retired();
+    if (b == 0) query_cam[slot] = in_set ? cam : -1;
+    if (a >= 0) a2q[((size_t)b * A + a) * cams + cam] = slot;
+    ref_pts2d[2 * (size_t)idx] = x;
+    ref_pts2d[2 * (size_t)idx + 1] = y;
+    ref_depth2d[idx] = d;
+    q2a[idx] = a;
+    is_center[idx] = ctr;
+    simpb::loads_retired();
+  }
+}
+
 inline int status() { return simpb_check_launch(); }
 inline void clear_stale() { (void)hipGetLastError(); }  // errors left by the caller's earlier runtime calls
 
@@ -284,5 +432,21 @@ extern "C" int simpb_aggregate_2d_to_3d(float* out_q, float* out_pos, const floa
   hipLaunchKernelGGL(aggregate_kernel, dim3(num_anchors, batch_size), dim3(64), 0, static_cast<hipStream_t>(stream),
                      out_q, out_pos, q3d, pos3d, q2d, pos2d, alpha, a2q, num_anchors, num_cams, num_query,
                      channels / 4);
+  return status();
+}
+
+extern "C" int simpb_alloc_static(unsigned char* flag, float* sel_xy, float* depth, int* count, int* order, int* group_start,
+                                  int* overflow, float* ref_pts2d, float* ref_depth2d, int* q2a, int* is_center, int* a2q,
+                                  int* query_cam, const float* anchor, const float* projection_mat, int batch_size,
+                                  int num_anchors, int num_cams, int capacity, float img_w, float img_h, float limit_w,
+                                  float limit_l, float limit_h, void* stream) {
+  if (!flag || !sel_xy || !depth || !count || !order || !group_start || !overflow || !ref_pts2d || !ref_depth2d || !q2a ||
+      !is_center || !a2q || !query_cam || !anchor || !projection_mat || batch_size <= 0 || num_anchors <= 0 ||
+      num_cams <= 0 || num_cams > 64 || capacity <= 0)
+    return SIMPB_EINVAL;
+  clear_stale();
+  hipLaunchKernelGGL(alloc_static_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), flag, sel_xy, depth, count,
+                     order, group_start, overflow, ref_pts2d, ref_depth2d, q2a, is_center, a2q, query_cam, anchor,
+                     projection_mat, batch_size, num_anchors, num_cams, capacity, img_w, img_h, limit_w, limit_l, limit_h);
   return status();
 }

@@ -11,6 +11,11 @@ from .ops import _ptr, _require_gpu, _stream
 from .registry import PLUGIN_LAYERS
 
 
+# True: with a fixed capacity the allocation steps run as ONE launch (simpb_alloc_static); False: one launch per step
+# (the route the exact-size mode always takes), also the cross-check in tests.
+FUSED_STATIC = True
+
+
 class Allocation2D:
     """Index form of one allocation: what the reference spreads over ref_trans_matrix /
     ref_center_matrix / query_groups."""
@@ -74,12 +79,14 @@ class DynamicQueryAllocation(nn.Module):
         depth = torch.empty(bs, cams, num_anchor, device=dev)
         lw, ll, lh = (float(v) for v in self.limit_anchor_size)
         st = _stream()
-        _lib.check(lib.simpb_alloc_project(_ptr(flag), _ptr(sel_xy), _ptr(depth), _ptr(anchor3d), _ptr(proj), bs,
-                                           num_anchor, cams, img_w, img_h, lw, ll, lh, st), "simpb_alloc_project")
         count = torch.empty(bs, cams, dtype=torch.int32, device=dev)
         order = torch.empty(bs, cams, num_anchor, dtype=torch.int32, device=dev)
-        _lib.check(lib.simpb_alloc_compact(_ptr(count), _ptr(order), _ptr(flag), bs, num_anchor, cams, st),
-                   "simpb_alloc_compact")
+        static = capacity is not None and FUSED_STATIC and cams <= 64
+        if not static:
+            _lib.check(lib.simpb_alloc_project(_ptr(flag), _ptr(sel_xy), _ptr(depth), _ptr(anchor3d), _ptr(proj), bs,
+                                               num_anchor, cams, img_w, img_h, lw, ll, lh, st), "simpb_alloc_project")
+            _lib.check(lib.simpb_alloc_compact(_ptr(count), _ptr(order), _ptr(flag), bs, num_anchor, cams, st),
+                       "simpb_alloc_compact")
         overflow = None
         if capacity is None:
             meta = count.max(dim=0).values.tolist()  # the one device->host sync (allocation.py:91-94)
@@ -94,8 +101,9 @@ class DynamicQueryAllocation(nn.Module):
             overflow = overflow_out if overflow_out is not None else torch.empty(1, dtype=torch.int32, device=dev)
             if overflow.dtype != torch.int32 or overflow.numel() != 1 or overflow.device != dev:
                 raise ValueError("overflow_out must be one i32 element on the anchors' device")
-            _lib.check(lib.simpb_alloc_group_start(_ptr(group_start), _ptr(overflow), _ptr(count), bs, cams, n2, st),
-                       "simpb_alloc_group_start")
+            if not static:
+                _lib.check(lib.simpb_alloc_group_start(_ptr(group_start), _ptr(overflow), _ptr(count), bs, cams, n2, st),
+                           "simpb_alloc_group_start")
         ref_pts2d = torch.empty(bs, n2, 2, device=dev)
         ref_depth2d = torch.empty(bs, n2, 1, device=dev)
         out = Allocation2D()
@@ -108,10 +116,17 @@ class DynamicQueryAllocation(nn.Module):
         out.count = count
         out.group_start = group_start
         out.overflow = overflow
-        _lib.check(lib.simpb_alloc_scatter(_ptr(ref_pts2d), _ptr(ref_depth2d), _ptr(out.q2a), _ptr(out.is_center),
-                                           _ptr(out.a2q), _ptr(out.query_cam), _ptr(group_start), _ptr(count),
-                                           _ptr(order), _ptr(flag), _ptr(sel_xy), _ptr(depth), bs, num_anchor, cams, n2,
-                                           img_w, img_h, st), "simpb_alloc_scatter")
+        if static:
+            # fixed capacity: nothing returns to the host between the steps, so they are one launch
+            _lib.check(lib.simpb_alloc_static(_ptr(flag), _ptr(sel_xy), _ptr(depth), _ptr(count), _ptr(order), _ptr(group_start),
+                                              _ptr(overflow), _ptr(ref_pts2d), _ptr(ref_depth2d), _ptr(out.q2a),
+                                              _ptr(out.is_center), _ptr(out.a2q), _ptr(out.query_cam), _ptr(anchor3d), _ptr(proj),
+                                              bs, num_anchor, cams, n2, img_w, img_h, lw, ll, lh, st), "simpb_alloc_static")
+        else:
+            _lib.check(lib.simpb_alloc_scatter(_ptr(ref_pts2d), _ptr(ref_depth2d), _ptr(out.q2a), _ptr(out.is_center),
+                                               _ptr(out.a2q), _ptr(out.query_cam), _ptr(group_start), _ptr(count),
+                                               _ptr(order), _ptr(flag), _ptr(sel_xy), _ptr(depth), bs, num_anchor, cams, n2,
+                                               img_w, img_h, st), "simpb_alloc_scatter")
         self.last = out
         if capacity is not None:
             # static mode: the mask / count views of the reference's tuple (allocation.py:144) are only consumed by

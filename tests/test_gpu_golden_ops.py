@@ -61,6 +61,32 @@ def test_allocation_vs_reference_vectors():
     assert int(s.overflow.item()) == 0 and (s.query_cam.cpu().numpy()[n2:] == -1).all()
 
 
+@pytest.mark.parametrize("bs,capacity", [(1, 1536), (3, 2048), (2, 600)])
+def test_static_allocation_in_one_launch_equals_the_stepwise_kernels(bs, capacity):
+    """simpb_alloc_static (the five allocation launches of a replayed frame as one) against the step-by-step kernels the
+    reference vectors pin above: every table bit for bit, batched (max-over-batch group table, allocation.py:91-99) and in
+    the overflow case (capacity 600 < N2)."""
+    from simpb_amd.plugin import allocation
+    layer = allocation.DynamicQueryAllocation().eval()
+    metas = metas_to(synth.frame_metas(bs, 0), "cuda")
+    g = torch.Generator().manual_seed(bs)
+    anchor = torch.from_numpy(synth.anchors(900)).float()[None].repeat(bs, 1, 1)
+    anchor[..., :2] += torch.randn(bs, 900, 2, generator=g) * 3.0
+    anchor = anchor.cuda()
+    outs = []
+    for fused in (True, False):
+        old = allocation.FUSED_STATIC
+        try:
+            allocation.FUSED_STATIC = fused
+            a, pts, depth, _, _ = layer.allocate(anchor, metas, capacity=capacity)
+        finally:
+            allocation.FUSED_STATIC = old
+        outs.append([a.q2a, a.is_center, a.a2q, a.query_cam, a.count, a.group_start, a.overflow, pts, depth])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert int(outs[0][6].item()) == (1 if capacity == 600 else 0)
+
+
 def test_msda_module_vs_reference_vectors():
     """A6: QueryGroupMultiScaleDeformableAttention (product module: projections + msda_prep + grouped sampler kernel +
     output_proj + cat) against the reference's own per-camera loop output (ops.npz:msda.out)."""

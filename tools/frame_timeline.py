@@ -11,6 +11,11 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "alloc_project" in r["Kernel_Name"]]
 q = rows[marks[-4]]["Queue_Id"]
 lo, hi = marks[-7], marks[-4]      # alloc_project runs three times per frame: one whole frame between the marks
+if "--frames" in sys.argv:         # average over the last N frames instead
+    nf = int(sys.argv[sys.argv.index("--frames") + 1])
+    lo, hi = marks[-3 * nf - 1], marks[-1]
+else:
+    nf = 1
 
 
 def short(n):
@@ -40,6 +45,6 @@ for r in seq:
     f[2] += gap
     prev_end = max(prev_end, e)
 span = (prev_end - t0) / 1e3
-print(f"{len(seq)} kernels on the decoder queue: span {span:.0f} us = busy {busy:.0f} us + gaps {gaps:.0f} us")
+print(f"{len(seq) / nf:.0f} kernels per frame on the decoder queue: span {span / nf:.0f} us = busy {busy / nf:.0f} us + gaps {gaps / nf:.0f} us")
 for n, (c, d, g) in sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
-    print(f"{d:8.1f} us busy {g:7.1f} us gaps in front {c:4d}x {n}")
+    print(f"{d / nf:8.1f} us busy {g / nf:7.1f} us gaps in front {c / nf:6.1f}x {n}")

@@ -17,6 +17,25 @@ synth.load_procedural(model)
 model = model.cuda().fuse_conv_bn().half_backbone()
 torch.backends.cudnn.benchmark = True
 r = PipelinedRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"))
+DEC_ONLY = "--dec-only" in sys.argv   # for rocprofv3 --kernel-trace: decoder graph replays with nothing beside them
+if len(sys.argv) > 1 and not DEC_ONLY:
+    # --bb-drop N: the backbone stream loses one group of 8 CUs in every N groups (in every XCD, whichever way CU indices
+    # map to XCDs); the decoder stream keeps the whole chip
+    import ctypes
+    drop = int(sys.argv[1])
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (n_cu + 31) // 32
+    m = (ctypes.c_uint32 * words)()
+    kept = 0
+    for i in range(n_cu):
+        if (i // 8) % drop != 0:
+            m[i // 32] |= 1 << (i % 32)
+            kept += 1
+    h = ctypes.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), m) == 0
+    r.s_bb = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", 0))
+    print(f"backbone stream on {kept} of {n_cu} CUs", flush=True)
 imgs = [synth.images(1, f, wh).cuda() for f in range(4)]
 metas = [synth.frame_metas(1, f, wh) for f in range(60)]
 for f in range(24):
@@ -54,6 +73,10 @@ def both():
             r.head_graph[i & 1].replay()
 
 
+if DEC_ONLY:
+    dec()
+    torch.cuda.synchronize()
+    sys.exit(0)
 for name, fn in (("backbone graph alone", bb), ("decoder graph alone", dec), ("both streams side by side", both)):
     fn()
     print(f"{name:28s} {wall(fn):.3f} ms per frame", flush=True)
