@@ -12,11 +12,13 @@ extern "C" int simpb_check_launch(void);
 
 namespace {
 
+constexpr int kMaxStaticCams = 8;   // cameras of the static-capacity path (simpb_alloc_static)
+
 // ---- step 1: one thread per (batch, anchor, cam): 9 projected points -> flag, 2D ref, depth
 __global__ void alloc_project_kernel(unsigned char* __restrict__ flag, float* __restrict__ sel_xy,
                                      float* __restrict__ depth, const float* __restrict__ anchor,
                                      const float* __restrict__ proj, int bs, int A, int cams, float img_w, float img_h,
-                                     float lim_w, float lim_l, float lim_h) {
+                                     float lim_w, float lim_l, float lim_h, int* __restrict__ a2q_fill) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= bs * A * cams) return;
   const int cam = idx % cams;
@@ -64,6 +66,7 @@ __global__ void alloc_project_kernel(unsigned char* __restrict__ flag, float* __
   sel_xy[2 * o] = sx;
   sel_xy[2 * o + 1] = sy;
   depth[o] = ctr_d;
+  if (a2q_fill) a2q_fill[idx] = -1;   // the (anchor, cam) -> slot table starts empty (same index space): no fill launch
 }
 
 // ---- step 2: one workgroup per (batch, cam): stable compaction of the flagged anchors
@@ -100,14 +103,39 @@ __global__ void alloc_scatter_kernel(float* __restrict__ ref_pts2d, float* __res
                                      const int* __restrict__ count, const int* __restrict__ order,
                                      const unsigned char* __restrict__ flag, const float* __restrict__ sel_xy,
                                      const float* __restrict__ depth, int bs, int A, int cams, int N2, float img_w,
-                                     float img_h) {
+                                     float img_h, int* __restrict__ group_start_out, int* __restrict__ overflow_out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= bs * N2) return;
   const int slot = idx % N2, b = idx / N2;
-  int cam = 0;
-  while (cam + 1 < cams && slot >= group_start[cam + 1]) ++cam;
-  const int rank = slot - group_start[cam];
-  const bool in_set = slot < group_start[cams];  // capacity slots past the last group belong to no camera
+  int cam = 0, g_lo = 0, g_end = 0;
+  int gs[kMaxStaticCams];
+  bool over = false;
+  if (group_start_out) {
+    // static capacity: every thread derives the group table from the counts itself (alloc_group_start_kernel's
+    // arithmetic: prefix sums of the max-over-batch counts clipped to the capacity N2); thread 0 publishes it below
+    int acc = 0;
+    bool found = false;
+#pragma unroll
+    for (int c = 0; c < kMaxStaticCams; ++c) {
+      gs[c] = acc;
+      if (c < cams) {
+        int m = 0;
+        for (int bb = 0; bb < bs; ++bb) m = max(m, count[bb * cams + c]);
+        const int lo = acc;
+        acc += m;
+        if (acc > N2) { over = true; acc = N2; }
+        if (!found && (slot < acc || c == cams - 1)) { cam = c; g_lo = lo; found = true; }
+        gs[c] = acc;
+      }
+    }
+    g_end = acc;
+  } else {
+    while (cam + 1 < cams && slot >= group_start[cam + 1]) ++cam;
+    g_lo = group_start[cam];
+    g_end = group_start[cams];
+  }
+  const int rank = slot - g_lo;
+  const bool in_set = slot < g_end;  // capacity slots past the last group belong to no camera
   const int bc = b * cams + cam;
   float x = 0.f, y = 0.f, d = 0.f;
   int a = -1, ctr = 0;
@@ -121,6 +149,13 @@ __global__ void alloc_scatter_kernel(float* __restrict__ ref_pts2d, float* __res
   }
   simpb::pin(x); simpb::pin(y); simpb::pin(d); simpb::pin(a); simpb::pin(ctr);
   simpb::loads_retired();  // store_fence.h: every table entry read, then the stores
+  if (group_start_out && idx == 0) {
+    group_start_out[0] = 0;
+#pragma unroll
+    for (int c = 0; c < kMaxStaticCams; ++c)
+      if (c < cams) group_start_out[c + 1] = gs[c];
+    overflow_out[0] = over ? 1 : 0;
+  }
   if (b == 0) query_cam[slot] = in_set ? cam : -1;
   if (a >= 0) a2q[((size_t)b * A + a) * cams + cam] = slot;
   ref_pts2d[2 * (size_t)idx] = x;
@@ -203,154 +238,6 @@ __global__ void aggregate_kernel(float* __restrict__ out_q, float* __restrict__ 
   }
 }
 
-// ---- the static-capacity allocation of one frame layer in ONE launch ---------------------------------------------------
-// In a replayed frame every kernel costs ~4.7 us of dispatch whatever it does, and steps 1-3 above are five launches of a few
-// hundred nanoseconds of work each (x 3 allocation layers per frame). With a fixed capacity nothing goes back to the host
-// between them, so one workgroup of 1 024 threads walks the steps itself, a workgroup barrier (+ device-scope fence: the
-// steps hand their results over through global memory) between two steps. Same arithmetic per element, same tables.
-__global__ __launch_bounds__(1024) void alloc_static_kernel(
-    unsigned char* __restrict__ flag, float* __restrict__ sel_xy, float* __restrict__ depth, int* __restrict__ count,
-    int* __restrict__ order, int* __restrict__ group_start, int* __restrict__ overflow, float* __restrict__ ref_pts2d,
-    float* __restrict__ ref_depth2d, int* __restrict__ q2a, int* __restrict__ is_center, int* __restrict__ a2q,
-    int* __restrict__ query_cam, const float* __restrict__ anchor, const float* __restrict__ proj, int bs, int A, int cams,
-    int N2, float img_w, float img_h, float lim_w, float lim_l, float lim_h) {
-  __shared__ int s_wave[16];
-  __shared__ int s_base;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  auto handover = [&]() {
-    __threadfence();
-    __syncthreads();
-  };
-  // step 1 (alloc_project_kernel) + the -1 fill of a2q
-  for (int idx = tid; idx < bs * A * cams; idx += 1024) {
-    const int cam = idx % cams;
-    const int a = (idx / cams) % A;
-    const int b = idx / (cams * A);
-    const float* an = anchor + ((size_t)b * A + a) * 11;
-    const float* P = proj + ((size_t)b * cams + cam) * 16;
-    const float cx = an[0], cy = an[1], cz = an[2];
-    const float sw = fminf(expf(an[3]), lim_w), sl = fminf(expf(an[4]), lim_l), sh = fminf(expf(an[5]), lim_h);
-    const float sn = an[6], cs = an[7];
-    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-    bool corner_valid = false;
-    float ctr_x = 0.f, ctr_y = 0.f, ctr_d = 0.f;
-    for (int k = 0; k < 9; ++k) {
-      float px, py, pz;
-      if (k < 8) {
-        const float ox = (((k >> 2) & 1) - 0.5f) * sw, oy = (((k >> 1) & 1) - 0.5f) * sl, oz = ((k & 1) - 0.5f) * sh;
-        px = cs * ox - sn * oy + cx;
-        py = sn * ox + cs * oy + cy;
-        pz = oz + cz;
-      } else {
-        px = cx; py = cy; pz = cz;
-      }
-      const float u = P[0] * px + P[1] * py + P[2] * pz + P[3];
-      const float v = P[4] * px + P[5] * py + P[6] * pz + P[7];
-      const float d = P[8] * px + P[9] * py + P[10] * pz + P[11];
-      const float dc = fmaxf(d, 1e-5f);
-      const float x = u / dc, y = v / dc;
-      const bool inside = 0.f < x && x < img_w && 0.f < y && y < img_h;
-      if (k < 8) {
-        corner_valid = corner_valid || (d > 0.f && inside);
-        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
-        ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
-      } else {
-        ctr_x = x; ctr_y = y; ctr_d = d;
-      }
-    }
-    const bool center_valid = 0.f < ctr_x && ctr_x < img_w && 0.f < ctr_y && ctr_y < img_h;
-    float sx = (fminf(fmaxf(xmin, 0.f), img_w) + fminf(fmaxf(xmax, 0.f), img_w)) / 2.f;
-    float sy = (fminf(fmaxf(ymin, 0.f), img_h) + fminf(fmaxf(ymax, 0.f), img_h)) / 2.f;
-    if (center_valid) { sx = ctr_x; sy = ctr_y; }
-    int fl = center_valid ? 2 : (corner_valid ? 1 : 0);
-    simpb::pin(sx); simpb::pin(sy); simpb::pin(ctr_d); simpb::pin(fl);
-    simpb::loads_retired();
-    const size_t o = ((size_t)b * cams + cam) * A + a;
-    flag[o] = (unsigned char)fl;
-    sel_xy[2 * o] = sx;
-    sel_xy[2 * o + 1] = sy;
-    depth[o] = ctr_d;
-    a2q[idx] = -1;
-    simpb::loads_retired();
-  }
-  handover();
-  // step 2 (alloc_compact_kernel), one (batch, camera) list after the other
-  for (int bc = 0; bc < bs * cams; ++bc) {
-    const unsigned char* f = flag + (size_t)bc * A;
-    int* ord = order + (size_t)bc * A;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int a0 = 0; a0 < A; a0 += 1024) {
-      const int a = a0 + tid;
-      bool on = false;
-      if (a < A) on = f[a] != 0;
-      simpb::loads_retired();
-      const unsigned long long m = __ballot(on);
-      if (lane == 0) s_wave[wave] = __popcll(m);
-      __syncthreads();
-      int off = s_base;
-      for (int w = 0; w < wave; ++w) off += s_wave[w];
-      if (on) ord[off + __popcll(m & ((1ull << lane) - 1ull))] = a;
-      __syncthreads();
-      if (tid == 0) {
-        int t = 0;
-        for (int w = 0; w < 16; ++w) t += s_wave[w];
-        s_base += t;
-      }
-      __syncthreads();
-    }
-    if (tid == 0) count[bc] = s_base;
-  }
-  handover();
-  // group table (alloc_group_start_kernel)
-  if (tid == 0) {
-    int acc = 0;
-    bool over = false;
-    int gs[64];
-    for (int c = 0; c < cams; ++c) {
-      int m = 0;
-      for (int b = 0; b < bs; ++b) m = max(m, count[b * cams + c]);
-      acc += m;
-      if (acc > N2) { over = true; acc = N2; }
-      gs[c] = acc;
-    }
-    simpb::loads_retired();
-    group_start[0] = 0;
-    for (int c = 0; c < cams; ++c) group_start[c + 1] = gs[c];
-    overflow[0] = over ? 1 : 0;
-  }
-  handover();
-  // step 3 (alloc_scatter_kernel)
-  for (int idx = tid; idx < bs * N2; idx += 1024) {
-    const int slot = idx % N2, b = idx / N2;
-    int cam = 0;
-    while (cam + 1 < cams && slot >= group_start[cam + 1]) ++cam;
-    const int rank = slot - group_start[cam];
-    const bool in_set = slot < group_start[cams];
-    const int bc = b * cams + cam;
-    float x = 0.f, y = 0.f, d = 0.f;
-    int a = -1, ctr = 0;
-    if (in_set && rank < count[bc]) {
-      a = order[(size_t)bc * A + rank];
-      const size_t o = (size_t)bc * A + a;
-      x = sel_xy[2 * o] / img_w;
-      y = sel_xy[2 * o + 1] / img_h;
-      d = fabsf(depth[o]);
-      ctr = flag[o] == 2;
-    }
-    simpb::pin(x); simpb::pin(y); simpb::pin(d); simpb::pin(a); simpb::pin(ctr);
-    simpb::loads_retired();
-    if (b == 0) query_cam[slot] = in_set ? cam : -1;
-    if (a >= 0) a2q[((size_t)b * A + a) * cams + cam] = slot;
-    ref_pts2d[2 * (size_t)idx] = x;
-    ref_pts2d[2 * (size_t)idx + 1] = y;
-    ref_depth2d[idx] = d;
-    q2a[idx] = a;
-    is_center[idx] = ctr;
-    simpb::loads_retired();
-  }
-}
-
 inline int status() { return simpb_check_launch(); }
 inline void clear_stale() { (void)hipGetLastError(); }  // errors left by the caller's earlier runtime calls
 
@@ -366,7 +253,7 @@ extern "C" int simpb_alloc_project(unsigned char* flag, float* sel_xy, float* de
   clear_stale();
   hipLaunchKernelGGL(alloc_project_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), flag,
                      sel_xy, depth, anchor, projection_mat, batch_size, num_anchors, num_cams, img_w, img_h, limit_w,
-                     limit_l, limit_h);
+                     limit_l, limit_h, static_cast<int*>(nullptr));
   return status();
 }
 
@@ -405,7 +292,7 @@ extern "C" int simpb_alloc_scatter(float* ref_pts2d, float* ref_depth2d, int* q2
     const int n = batch_size * num_query;
     hipLaunchKernelGGL(alloc_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ref_pts2d, ref_depth2d, q2a,
                        is_center, a2q, query_cam, group_start, count, order, flag, sel_xy, depth, batch_size,
-                       num_anchors, num_cams, num_query, img_w, img_h);
+                       num_anchors, num_cams, num_query, img_w, img_h, static_cast<int*>(nullptr), static_cast<int*>(nullptr));
   }
   return status();
 }
@@ -442,11 +329,17 @@ extern "C" int simpb_alloc_static(unsigned char* flag, float* sel_xy, float* dep
                                   float limit_l, float limit_h, void* stream) {
   if (!flag || !sel_xy || !depth || !count || !order || !group_start || !overflow || !ref_pts2d || !ref_depth2d || !q2a ||
       !is_center || !a2q || !query_cam || !anchor || !projection_mat || batch_size <= 0 || num_anchors <= 0 ||
-      num_cams <= 0 || num_cams > 64 || capacity <= 0)
+      num_cams <= 0 || num_cams > kMaxStaticCams || capacity <= 0)
     return SIMPB_EINVAL;
   clear_stale();
-  hipLaunchKernelGGL(alloc_static_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), flag, sel_xy, depth, count,
-                     order, group_start, overflow, ref_pts2d, ref_depth2d, q2a, is_center, a2q, query_cam, anchor,
-                     projection_mat, batch_size, num_anchors, num_cams, capacity, img_w, img_h, limit_w, limit_l, limit_h);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int n = batch_size * num_anchors * num_cams;
+  hipLaunchKernelGGL(alloc_project_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flag, sel_xy, depth, anchor, projection_mat,
+                     batch_size, num_anchors, num_cams, img_w, img_h, limit_w, limit_l, limit_h, a2q);
+  hipLaunchKernelGGL(alloc_compact_kernel, dim3(batch_size * num_cams), dim3(256), 0, s, count, order, flag, num_anchors);
+  const int ns = batch_size * capacity;
+  hipLaunchKernelGGL(alloc_scatter_kernel, dim3((ns + 255) / 256), dim3(256), 0, s, ref_pts2d, ref_depth2d, q2a, is_center, a2q,
+                     query_cam, static_cast<const int*>(nullptr), count, order, flag, sel_xy, depth, batch_size, num_anchors,
+                     num_cams, capacity, img_w, img_h, group_start, overflow);
   return status();
 }

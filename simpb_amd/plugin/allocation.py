@@ -11,7 +11,7 @@ from .ops import _ptr, _require_gpu, _stream
 from .registry import PLUGIN_LAYERS
 
 
-# True: with a fixed capacity the allocation steps run as ONE launch (simpb_alloc_static); False: one launch per step
+# True: with a fixed capacity the allocation steps run as three launches (simpb_alloc_static); False: five, one per step
 # (the route the exact-size mode always takes), also the cross-check in tests.
 FUSED_STATIC = True
 
@@ -81,7 +81,7 @@ class DynamicQueryAllocation(nn.Module):
         st = _stream()
         count = torch.empty(bs, cams, dtype=torch.int32, device=dev)
         order = torch.empty(bs, cams, num_anchor, dtype=torch.int32, device=dev)
-        static = capacity is not None and FUSED_STATIC and cams <= 64
+        static = capacity is not None and FUSED_STATIC and cams <= 8
         if not static:
             _lib.check(lib.simpb_alloc_project(_ptr(flag), _ptr(sel_xy), _ptr(depth), _ptr(anchor3d), _ptr(proj), bs,
                                                num_anchor, cams, img_w, img_h, lw, ll, lh, st), "simpb_alloc_project")
@@ -117,7 +117,7 @@ class DynamicQueryAllocation(nn.Module):
         out.group_start = group_start
         out.overflow = overflow
         if static:
-            # fixed capacity: nothing returns to the host between the steps, so they are one launch
+            # fixed capacity: nothing returns to the host between the steps: fill and group table ride in steps 1 and 3
             _lib.check(lib.simpb_alloc_static(_ptr(flag), _ptr(sel_xy), _ptr(depth), _ptr(count), _ptr(order), _ptr(group_start),
                                               _ptr(overflow), _ptr(ref_pts2d), _ptr(ref_depth2d), _ptr(out.q2a),
                                               _ptr(out.is_center), _ptr(out.a2q), _ptr(out.query_cam), _ptr(anchor3d), _ptr(proj),

@@ -62,8 +62,8 @@ def test_allocation_vs_reference_vectors():
 
 
 @pytest.mark.parametrize("bs,capacity", [(1, 1536), (3, 2048), (2, 600)])
-def test_static_allocation_in_one_launch_equals_the_stepwise_kernels(bs, capacity):
-    """simpb_alloc_static (the five allocation launches of a replayed frame as one) against the step-by-step kernels the
+def test_static_allocation_call_equals_the_stepwise_kernels(bs, capacity):
+    """simpb_alloc_static (the five allocation launches of a replayed frame as three) against the step-by-step kernels the
     reference vectors pin above: every table bit for bit, batched (max-over-batch group table, allocation.py:91-99) and in
     the overflow case (capacity 600 < N2)."""
     from simpb_amd.plugin import allocation
