@@ -252,10 +252,22 @@ class SimPBHead(BaseModule):
         last = len(self.operation_order) - 1
         # static mode: the overflow flags of the frame's allocation layers in one tensor; the frame-end commit of the
         # bank holds back when any is set, so that the caller can re-run the frame (runner.py) on untouched state
-        overflow = None
+        overflow = hold = None
         if cap is not None:
-            overflow = torch.zeros(sum(op == "allocation" for op in self.operation_order), dtype=torch.int32,
-                                   device=anchor.device)
+            n_alloc = sum(op == "allocation" for op in self.operation_order)
+            chain = metas.get("overflow_chain")
+            if chain is not None:
+                # (flags i32 [rows, n_alloc] owned by the caller, this frame's row): the commit also holds back when a flag
+                # of the OTHER rows is set, i.e. when the frame decoded just before this one (enqueued while its own flags
+                # had not reached the host yet: runner.PipelinedRunner) is going to be re-run
+                flags, row = chain
+                if flags.dtype != torch.int32 or flags.dim() != 2 or flags.shape[1] != n_alloc or not flags.is_contiguous():
+                    raise ValueError("overflow_chain: (contiguous i32 [rows, allocation layers] tensor, row)")
+                overflow = flags[row]
+                overflow.zero_()
+                hold = flags.view(-1)
+            else:
+                overflow = hold = torch.zeros(n_alloc, dtype=torch.int32, device=anchor.device)
 
         for i, op in enumerate(self.operation_order):
             layer = self.layers[i]
@@ -347,7 +359,7 @@ class SimPBHead(BaseModule):
             "alloc_list": alloc_list, "overflow": overflow,
         }
         ids = self.instance_bank.cache_and_assign_ids(instance_feature, anchor, cls, metas, self.decoder.score_threshold,
-                                                      hold=overflow)
+                                                      hold=hold)
         if ids is None:
             self.instance_bank.cache(instance_feature, anchor, cls, metas, feature_maps)
             ids = self.instance_bank.get_instance_id(cls, anchor, self.decoder.score_threshold)

@@ -155,10 +155,17 @@ class PipelinedRunner(FrameRunner):
     The decoder of frame t needs the bank the decoder of frame t-1 wrote, so decoders cannot overlap
     each other; but backbone+FPN of the next frame depends on nothing but its images. Many decoder
     kernels are small and leave most of the 256 CUs idle, while the convolutions fill the chip, so the
-    two run side by side on separate HIP streams: step(t) launches backbone(t) and decoder(t-1) together
-    and returns the detections of frame t-1 (one frame of latency for throughput; flush() returns the
-    last frame). Two feature buffers alternate; each (backbone, decoder) x (buffer) pair is its own
-    hipGraph once warm, so the steady state is two graph launches per step."""
+    two run side by side on separate HIP streams: step(t) launches backbone(t) and returns the detections of
+    frame t-1 (one frame of latency for throughput; flush() returns the last frame). Two feature buffers
+    alternate; each (backbone, decoder) x (buffer) pair is its own hipGraph once warm, so the steady state is two
+    graph launches per step.
+
+    The decoder of frame t is ENQUEUED in step(t) as well, behind backbone(t) (an event) and behind decoder(t-1)
+    (stream order): when step(t) returns with the detections of t-1, the decoder stream already holds its next
+    job, and the ~0.25 ms of host work between two steps (record finish, metadata staging, graph launches) no
+    longer idles it. That decoder runs before the host has seen decoder(t-1)'s overflow flags, so the bank commit
+    is chained on the device: a frame's commit also holds back when the flags of the frame enqueued before it are
+    set (`overflow_chain`, plugin/head.py), and collect() then re-runs both, in order, on the state frame t-1 found."""
 
     def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True):
         super().__init__(model, batch_size, image_hw, capacity, device, use_graph)
@@ -176,8 +183,14 @@ class PipelinedRunner(FrameRunner):
         self.head_graph = [None, None]
         self.head_out = [None, None]
         self.head_runs = [0, 0]
-        self.pending = None                 # (frame index, metas) whose features exist but decoder has not run
         self.count = 0
+        n_alloc = sum(op == "allocation" for op in self.head.operation_order)
+        self.flags = torch.zeros(2, n_alloc, dtype=torch.int32, device=dev)   # overflow flags, one row per feature slot
+        self.queue = []                     # decoders in flight, oldest first: dict(slot, metas, prev, warm, rec)
+        self.last_metas = None              # metas of the frame whose decoder was enqueued last
+        self.bb_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.staged = None                  # event: the pinned staging buffers have been copied to the device
+        self.host = [None, None]            # pinned read-back buffers per slot: (rec3d, rec2d, flags)
 
     def _run_backbone(self, slot, force_eager):
         """Enqueue backbone+FPN of the image in slot `slot` on s_bb."""
@@ -240,55 +253,56 @@ class PipelinedRunner(FrameRunner):
                     self.head_runs[slot] += 1
             return rec
 
-    def _enqueue_readback(self, rec):
+    def _enqueue_readback(self, slot, rec):
         with torch.cuda.stream(self.s_head):
-            if self.host3d is None or self.host2d.shape != rec[1].shape:
-                self.host3d = torch.empty(rec[0].shape, dtype=rec[0].dtype).pin_memory()
-                self.host2d = torch.empty(rec[1].shape, dtype=rec[1].dtype).pin_memory()
-                self.host_flag = torch.empty(rec[2].shape, dtype=rec[2].dtype).pin_memory()
-            self.host3d.copy_(rec[0], non_blocking=True)
-            self.host2d.copy_(rec[1], non_blocking=True)
-            self.host_flag.copy_(rec[2], non_blocking=True)
+            h = self.host[slot]
+            if h is None or h[1].shape != rec[1].shape:
+                h = tuple(torch.empty(r.shape, dtype=r.dtype).pin_memory() for r in rec)
+                self.host[slot] = h
+            for dst, src in zip(h, rec):
+                dst.copy_(src, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.s_head)
+        return done
 
-    def _collect(self, ctx):
-        """ctx = (slot, metas, warm, rec) of the decoder launch being waited for."""
-        pslot, metas, warm, rec = ctx
-        self.s_head.synchronize()
-        while bool(self.host_flag.any()):
-            # overflow: the bank's commit held back, the features of the frame still sit in their slot, the staged
-            # decoder inputs are untouched -> re-run this decoder eagerly with a larger slot array
-            self._grow()
-            if not warm:
-                self.head.instance_bank.reset()  # a cold frame starts from an empty bank again
-            rec = self._run_head(pslot, self._device_metas(metas), metas["img_metas"][0]["aug_config"], warm, True)
-            self._enqueue_readback(rec)
-            self.s_head.synchronize()
-        self.last_rec3d = rec[0]
-        self.prev_metas = dict(img_metas=metas["img_metas"])
-        results = SparseBox3DDecoder.decode_static_host(self.host3d.numpy(), self.host2d.numpy(), self.head.num_cams)
-        return [{"img_bbox": r} for r in results]
-
-    def _finish(self, slot, metas, warm, rec):
-        self._enqueue_readback(rec)
-        return self._collect((slot, metas, warm, rec))
-
-    def _stage_head_inputs(self, metas):
-        """Per-frame decoder inputs (projection matrices, ego-motion, time step) of the PENDING frame."""
+    def _stage_head_inputs(self, metas, prev):
+        """Per-frame decoder inputs (projection matrices, ego-motion, time step) of a frame; prev = the metas of the
+        frame before it (None for a cold frame)."""
+        if self.staged is not None:
+            self.staged.synchronize()   # the previous frame's copies out of the pinned buffers (long done in practice)
         with torch.cuda.stream(self.s_head):
             self.pin_proj.copy_(metas["projection_mat"] if not metas["projection_mat"].is_cuda else metas["projection_mat"].cpu())
             self.proj.copy_(self.pin_proj, non_blocking=True)
-            if self.prev_metas is not None:
+            if prev is not None:
                 for i, m in enumerate(metas["img_metas"]):
-                    t = m["T_global_inv"] @ self.prev_metas["img_metas"][i]["T_global"]
+                    t = m["T_global_inv"] @ prev["img_metas"][i]["T_global"]
                     self.pin_t[i] = torch.from_numpy(np.asarray(t, np.float32))
-                    self.pin_dt[i] = float(m["timestamp"] - self.prev_metas["img_metas"][i]["timestamp"])
+                    self.pin_dt[i] = float(m["timestamp"] - prev["img_metas"][i]["timestamp"])
                 self.t_buf.copy_(self.pin_t, non_blocking=True)
                 self.dt_buf.copy_(self.pin_dt, non_blocking=True)
+            self.staged = torch.cuda.Event()
+            self.staged.record(self.s_head)
+
+    def _head_metas(self, metas, slot, warm):
+        out = dict(projection_mat=self.proj, image_wh=self.wh, image_wh_host=self.wh_host, img_metas=metas["img_metas"],
+                   overflow_chain=(self.flags, slot))
+        if warm:
+            out["bank_inputs"] = (self.t_buf, self.dt_buf)
+        return out
+
+    def _enqueue_decoder(self, slot, metas, prev, force_eager):
+        """Stage the inputs of the frame whose features sit in `slot` and enqueue its decoder + read-back on s_head."""
+        warm = prev is not None
+        self.prev_metas = prev   # (what the base class's helpers look at)
+        self._stage_head_inputs(metas, prev)
+        rec = self._run_head(slot, self._head_metas(metas, slot, warm), metas["img_metas"][0]["aug_config"], warm, force_eager)
+        done = self._enqueue_readback(slot, rec)
+        return dict(slot=slot, metas=metas, prev=prev, warm=warm, rec=rec, done=done)
 
     @torch.no_grad()
     def launch(self, img, metas, force_eager=False):
-        """Enqueue backbone(t) and decoder(t-1) without waiting for either (several runners -- several
-        independent camera streams on one GPU -- can be launched back to back and collected after)."""
+        """Enqueue backbone(t) and decoder(t) without waiting for either (several runners -- several independent
+        camera streams on one GPU -- can be launched back to back and collected after)."""
         slot = self.count % 2
         cur = torch.cuda.current_stream()
         self.s_bb.wait_stream(cur)
@@ -296,23 +310,47 @@ class PipelinedRunner(FrameRunner):
         with torch.cuda.stream(self.s_bb):
             self.imgs[slot].copy_(img, non_blocking=True)
         self._run_backbone(slot, force_eager)
-        self._inflight = None
-        if self.pending is not None:
-            pslot, pmetas = self.pending
-            self._stage_head_inputs(pmetas)
-            warm = self.prev_metas is not None
-            rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"], warm, force_eager)
-            self._enqueue_readback(rec)
-            self._inflight = (pslot, pmetas, warm, rec)
-        self._next_pending = (slot, metas)
+        self.bb_done[slot].record(self.s_bb)
+        self.s_head.wait_event(self.bb_done[slot])
+        prev = dict(img_metas=self.last_metas["img_metas"]) if self.last_metas is not None else None
+        self.queue.append(self._enqueue_decoder(slot, metas, prev, force_eager))
+        self.last_metas = metas
+        self.count += 1
+
+    def _finish(self, job):
+        """Wait for a decoder in flight, re-run it (and whatever was enqueued behind it) if its 2D set overflowed,
+        return its detections."""
+        job["done"].synchronize()
+        h = self.host[job["slot"]]
+        if bool(h[2].any()):
+            # overflow: this frame's bank commit held back, and so did the commit of the frame enqueued behind it
+            # (overflow_chain); the features of both still sit in their slots -> re-run them in order, eagerly, with a
+            # larger slot array (the graphs are re-captured at the new capacity afterwards)
+            behind = list(self.queue)
+            self.queue.clear()
+            self.s_head.synchronize()
+            with torch.cuda.stream(self.s_head):
+                self.flags.zero_()   # the speculative decoder behind may have left flags of its own: the re-runs start clean
+            while bool(h[2].any()):
+                self._grow()
+                if not job["warm"]:
+                    self.head.instance_bank.reset()  # a cold frame starts from an empty bank again
+                job = self._enqueue_decoder(job["slot"], job["metas"], job["prev"], True)
+                job["done"].synchronize()
+                h = self.host[job["slot"]]
+            for b in behind:
+                self.queue.append(self._enqueue_decoder(b["slot"], b["metas"], b["prev"], True))
+        self.last_rec3d = job["rec"][0]
+        self.prev_metas = dict(img_metas=job["metas"]["img_metas"])
+        results = SparseBox3DDecoder.decode_static_host(h[0].numpy(), h[1].numpy(), self.head.num_cams)
+        return [{"img_bbox": r} for r in results]
 
     def collect(self):
-        """Wait for what launch() enqueued; returns the detections of frame t-1 (None the first time)."""
-        results = self._collect(self._inflight) if self._inflight is not None else None
-        self.s_bb.synchronize()
-        self.pending = self._next_pending
-        self.count += 1
-        return results
+        """Returns the detections of frame t-1 (None the first time): waits for the decoder enqueued one step ago,
+        not for what launch() just enqueued."""
+        if len(self.queue) < 2:
+            return None
+        return self._finish(self.queue.pop(0))
 
     def step(self, img, metas, force_eager=False):
         """Feed frame t; returns the detections of frame t-1 (None on the very first call)."""
@@ -321,12 +359,8 @@ class PipelinedRunner(FrameRunner):
 
     @torch.no_grad()
     def flush(self):
-        """Run the decoder of the last fed frame and return its detections."""
-        if self.pending is None:
-            return None
-        pslot, pmetas = self.pending
-        self._stage_head_inputs(pmetas)
-        warm = self.prev_metas is not None
-        rec = self._run_head(pslot, self._device_metas(pmetas), pmetas["img_metas"][0]["aug_config"], warm, True)
-        self.pending = None
-        return self._finish(pslot, pmetas, warm, rec)
+        """Wait for the decoder of the last fed frame and return its detections."""
+        out = None
+        while self.queue:
+            out = self._finish(self.queue.pop(0))
+        return out

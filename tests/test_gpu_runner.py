@@ -173,6 +173,30 @@ def test_pipelined_runner_overflow_reruns_the_decoder():
     assert runner.stats["overflow"] >= 1 and runner.capacity > 768, (runner.stats, runner.capacity)
 
 
+def test_pipelined_runner_overflow_with_a_decoder_already_enqueued_behind():
+    """Overflow in the middle of a warm stream of the pipelined runner: the slot array is shrunk before frame 1 is fed,
+    so decoder(1) overflows with a warm bank WHILE decoder(2) has already been enqueued behind it (the host had not seen
+    the flags yet). The bank commit of both holds back on the device (overflow_chain), both are re-run in order at a
+    grown capacity, and the stream's detections and track ids are the golden ones."""
+    g = load_golden("head_r50.npz")
+    spec = spec_of(g)
+    model, runner = _golden_pipelined_runner(spec)
+    outs = []
+    for f in range(spec["frames"]):
+        if f == 1:
+            runner.capacity = runner.head.static_capacity = 640
+            runner._drop_graphs()
+        model.stage(f)
+        torch.cuda.synchronize()
+        outs.append(runner.step(runner.img, synth.frame_metas(1, f, spec["image_wh"], jump=spec["jump"])))
+    outs.append(runner.flush())
+    assert outs[0] is None and not runner.queue
+    for f in range(spec["frames"]):
+        compare_result(outs[f + 1][0]["img_bbox"], g, f"f{f}.res0.")
+    assert runner.stats["overflow"] >= 1 and runner.capacity > 640, (runner.stats, runner.capacity)
+    assert int(runner.flags.abs().sum()) == 0
+
+
 def test_config3_eight_streams_per_gpu_vs_golden():
     """BASELINE config #3 shape on one GPU: 8 independent camera streams at R50 704x256, each its own pipelined runner
     (bs = 1, the reference's own test setting), launched back to back and collected together like bench.py --streams 8.

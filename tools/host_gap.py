@@ -1,5 +1,6 @@
-"""Where a pipelined step's wall time goes on the HOST: launch() (staging + graph launches), the wait inside collect(),
-and the numpy finish -- i.e. how long the GPU sits idle between two steps of one stream.
+"""Where a pipelined step's wall time goes on the HOST: launch() (staging + graph launches), the wait for the decoder
+enqueued one step earlier, and the numpy finish. Since the decoder of a frame is enqueued in the step that feeds it, the
+decoder stream has its next job while the host does all this.
 usage: python tools/host_gap.py"""
 import os
 import sys
@@ -40,10 +41,9 @@ n = 100
 t0 = time.perf_counter()
 for f in range(20, 20 + n):
     a = time.perf_counter()
-    r.launch(imgs[f % 4], metas[f])
+    r.launch(imgs[f % 4], metas[f])       # backbone(f) and decoder(f) enqueued; decoder(f-1) is what collect() waits for
     b = time.perf_counter()
-    r.s_head.synchronize()
-    r.s_bb.synchronize()
+    r.queue[0]["done"].synchronize()
     c = time.perf_counter()
     r.collect()
     d = time.perf_counter()
