@@ -18,7 +18,7 @@ model = model.cuda().fuse_conv_bn().half_backbone()
 torch.backends.cudnn.benchmark = True
 r = PipelinedRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"))
 DEC_ONLY = "--dec-only" in sys.argv   # for rocprofv3 --kernel-trace: decoder graph replays with nothing beside them
-if len(sys.argv) > 1 and not DEC_ONLY:
+if len(sys.argv) > 1 and not DEC_ONLY and "--co" not in sys.argv:
     # --bb-drop N: the backbone stream loses one group of 8 CUs in every N groups (in every XCD, whichever way CU indices
     # map to XCDs); the decoder stream keeps the whole chip
     import ctypes
@@ -73,6 +73,40 @@ def both():
             r.head_graph[i & 1].replay()
 
 
+if "--co" in sys.argv:
+    # the decoder graph beside ONE kind of backbone kernel looping on the other stream: which ingredient of the backbone
+    # slows the decoder (matrix load, memory traffic, nothing in particular)?
+    from simpb_amd.plugin import ops
+    x256 = torch.randn(6, 256, 64, 176, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    x64 = torch.randn(6, 64, 64, 176, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    w3 = (torch.randn(256, 256, 3, 3, device="cuda") * 0.02).half().contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn(256, 64, 1, 1, device="cuda") * 0.05).half()
+    b256 = torch.zeros(256, device="cuda").half()
+    res = torch.randn(6, 256, 64, 176, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    tok16 = torch.randn(89760, 256, device="cuda").half()
+    vw, vb = torch.randn(256, 256, device="cuda") * 0.05, torch.zeros(256, device="cuda")
+    big = torch.randn(46 * 1024 * 1024, device="cuda")
+    big2 = torch.empty_like(big)
+    co = {"conv3x3": (lambda: ops.conv3x3_nhwc(x256, w3, b256, True, 1), 145.0),
+          "conv1x1": (lambda: ops.conv1x1_nhwc(x64, w1, b256, res, True, 1), 25.0),
+          "value_proj": (lambda: ops.linear_split(tok16, vw, vb), 75.0),
+          "copy": (lambda: big2.copy_(big), 75.0)}
+    m = 20
+    for name, (fn, us) in co.items():
+        reps = int(m * 2600 / us * 1.3)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(r.s_bb):
+            for _ in range(reps):
+                fn()
+        with torch.cuda.stream(r.s_head):
+            a.record()
+            for i in range(m):
+                r.head_graph[i & 1].replay()
+            b.record()
+        torch.cuda.synchronize()
+        print(f"decoder graph beside a loop of {name:10s}: {a.elapsed_time(b) / m:.3f} ms per frame", flush=True)
+    sys.exit(0)
 if DEC_ONLY:
     dec()
     torch.cuda.synchronize()
