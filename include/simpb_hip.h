@@ -285,6 +285,8 @@ typedef struct simpb_mlp_args {
                             * layout for the others (4-row kernel on the 4x4 matrix blocks: 225 workgroups for 900 rows) */
   int reserved;
   simpb_mlp_chain chain[SIMPB_MLP_MAX_CHAINS];
+  const int* m_live;       /* device int or NULL: rows >= *m_live are capacity slots of the static 2D query set; workgroups
+                            * whose rows are all past it write zeros and leave (as in simpb_gemm_f32) */
 } simpb_mlp_args;
 int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream);
 

@@ -54,6 +54,21 @@ __device__ __forceinline__ float post_stage(const simpb_mlp_chain& ch, float v, 
   return v;
 }
 
+// Rows >= *m_live are capacity slots of the static 2D query set (no camera, nothing reads them): a workgroup whose rows are
+// all dead writes zeros and leaves -- a quarter of the 1 536-slot launches' workgroups at N2 ~ 1 130.
+__device__ __forceinline__ bool skip_dead_rows(const simpb_mlp_args& args, const simpb_mlp_chain& ch, int row0, int rows,
+                                               int tid, int nthreads) {
+  if (!args.m_live || row0 < *args.m_live) return false;
+  int width = ch.in_mode == SIMPB_MLP_IN_SINE2D ? 256 : ch.in_dim;
+  for (int o = 0; o < ch.n_ops; ++o)
+    if (ch.ops[o].type == SIMPB_MLP_LINEAR) width = ch.ops[o].out_dim;
+  for (int idx = tid; idx < rows * width; idx += nthreads) {
+    const int r = idx / width, t = idx - r * width;
+    if (row0 + r < args.num_rows) ch.out[(size_t)(row0 + r) * ch.ldo + t] = 0.f;
+  }
+  return true;
+}
+
 template <int R, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void mlp_chain_kernel(simpb_mlp_args args) {
   constexpr int kThreads = WAVES * 64;
@@ -62,6 +77,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_chain_kernel(simpb_mlp_args ar
   const simpb_mlp_chain& ch = args.chain[blockIdx.y];
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * R;
+  if (skip_dead_rows(args, args.chain[blockIdx.y], row0, R, threadIdx.x, WAVES * 64)) return;
   const int N = args.num_rows;
 
   // ---- input stage
@@ -283,6 +299,7 @@ __global__ __launch_bounds__(kMW * 64) void mlp_chain_mfma_kernel(simpb_mlp_args
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * kMR;
+  if (skip_dead_rows(args, args.chain[blockIdx.y], row0, kMR, threadIdx.x, kMW * 64)) return;
   const int N = args.num_rows;
   SIMPB_STAMP(0);
 
@@ -505,6 +522,7 @@ __global__ __launch_bounds__(256) void mlp_chain_r4_kernel(simpb_mlp_args args) 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * kR4;
+  if (skip_dead_rows(args, args.chain[blockIdx.y], row0, kR4, threadIdx.x, 256)) return;
   const int N = args.num_rows;
 
   if (ch.in_mode == SIMPB_MLP_IN_SINE2D) {

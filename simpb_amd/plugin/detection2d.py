@@ -62,11 +62,11 @@ class SparseBox2DEncoder(BaseModule):
                 self.size_fc = embedding_layer(2)
                 self.output_fc = embedding_layer(self.embed_dims)
 
-    def forward(self, box_2d):
+    def forward(self, box_2d, m_live=None):
         if self.with_sin_embed:
             if box_2d.is_cuda and box_2d.shape[-1] == 2:
                 from . import fused  # sine embedding + the two Linear/ReLU/LN stages in one launch
-                return fused.chain_forward(self.query_embeddings2d, box_2d, sine=True)
+                return fused.chain_forward(self.query_embeddings2d, box_2d, sine=True, m_live=m_live)
             return self.query_embeddings2d(pos2posemb2d(box_2d))
         pos_feat = self.pos_fc(box_2d[..., :2])
         if not self.with_size:
@@ -104,7 +104,7 @@ class SparseBox2DRefinementModule(BaseModule):
         if self.with_cls_branch:
             nn.init.constant_(self.cls_layers[-1].bias, bias_init_with_prob(0.01))
 
-    def forward(self, instance_feature, anchor2d, anchor2d_embed, metas=None, return_cls=True, query_groups=None):
+    def forward(self, instance_feature, anchor2d, anchor2d_embed, metas=None, return_cls=True, query_groups=None, m_live=None):
         fused_ok = instance_feature.is_cuda
         if fused_ok:
             from . import fused
@@ -126,7 +126,7 @@ class SparseBox2DRefinementModule(BaseModule):
                 alpha_t = torch.empty(n, adim, device=xf.device)
                 jobs.append(dict(plan=fused.plan_of(self.alpha_layers), x=(xf, ldx, 0), out=(alpha_t, adim, 0)))
             if n:
-                fused.run_chains(jobs, n, xf.device)
+                fused.run_chains(jobs, n, xf.device, m_live=m_live)
             output = out_t.reshape(lead + (self.output_dim,))
         else:
             output = self.layers(instance_feature + anchor2d_embed)

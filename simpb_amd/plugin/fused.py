@@ -37,7 +37,7 @@ class _Chain(ctypes.Structure):
 
 class _Args(ctypes.Structure):
     _fields_ = [("num_rows", ctypes.c_int), ("num_chains", ctypes.c_int), ("weights_transposed", ctypes.c_int),
-                ("reserved", ctypes.c_int), ("chain", _Chain * MAX_CHAINS)]
+                ("reserved", ctypes.c_int), ("chain", _Chain * MAX_CHAINS), ("m_live", ctypes.c_void_p)]
 
 
 class ChainPlan:
@@ -140,14 +140,16 @@ def _rows(t, width):
     return flat, flat.stride(0)
 
 
-def run_chains(jobs, num_rows, device):
+def run_chains(jobs, num_rows, device, m_live=None):
     """jobs: list of dicts(plan, x=(tensor2d, ld, col), x2=(tensor2d, ld, col) or None, out=(tensor2d, ld, col),
     sine=bool, post=dict(kind, res=(tensor2d, ld), res_cols, div=tensor or None, div_rows, div_col0) or None).
-    All tensors f32 on `device`, 2-D views with unit inner stride."""
+    All tensors f32 on `device`, 2-D views with unit inner stride. m_live: device i32 [1] or None; rows past it are capacity
+    slots of the static 2D query set and come out as zeros (their workgroups do no work)."""
     if not jobs or len(jobs) > MAX_CHAINS:
         raise ValueError("1..8 chains per launch")
     args = _Args()
     args.num_rows, args.num_chains = int(num_rows), len(jobs)
+    args.m_live = m_live.data_ptr() if m_live is not None else None
     args.weights_transposed = 2 if ROWS4 else (1 if TRANSPOSED_WEIGHTS else 0)
     keep = []
     for c, job in enumerate(jobs):
@@ -181,7 +183,7 @@ def run_chains(jobs, num_rows, device):
     _lib.check(status, "simpb_mlp_chain_forward")
 
 
-def chain_forward(seq, x, x2=None, sine=False, post=None):
+def chain_forward(seq, x, x2=None, sine=False, post=None, m_live=None):
     """y = post(seq(x + x2)) for x [..., in_dim] on the GPU, one launch."""
     plan = plan_of(seq)
     xf, ldx = _rows(x, x.shape[-1])
@@ -193,5 +195,5 @@ def chain_forward(seq, x, x2=None, sine=False, post=None):
     out = torch.empty(n, plan.out_dim, device=x.device, dtype=torch.float32)
     job["out"] = (out, plan.out_dim, 0)
     if n:
-        run_chains([job], n, x.device)
+        run_chains([job], n, x.device, m_live=m_live)
     return out.reshape(x.shape[:-1] + (plan.out_dim,))

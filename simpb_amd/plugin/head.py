@@ -290,7 +290,8 @@ class SimPBHead(BaseModule):
                 if cap is not None and batch_size == 1 and alloc.group_start is not None:
                     self._m_live = alloc.group_start[self.num_cams: self.num_cams + 1]
                 instance_feature = gather_rows(instance_feature, alloc.q2a)  # :438
-                anchor_embed2d = self.anchor_encoder2d(anchor2d)
+                anchor_embed2d = (self.anchor_encoder2d(anchor2d, m_live=self._m_live) if self._m_live is not None
+                                  else self.anchor_encoder2d(anchor2d))
                 ref_pts2d_list.append(anchor2d[..., :2])
                 self.instance_status = "2d"
             elif op == "aggregation":
@@ -314,8 +315,9 @@ class SimPBHead(BaseModule):
                                          query_cam=alloc.query_cam, m_live=self._m_live,
                                          keep_parts=dense.ENABLED and self._next_is_ffn(i), **enc)
             elif op == "refine2d":
+                kw = dict(m_live=self._m_live) if self._m_live is not None else {}
                 anchor2d, cls2d, depth2d, alpha2d = layer(instance_feature, anchor2d, anchor_embed2d, metas=metas,
-                                                          query_groups=ref_query_groups)
+                                                          query_groups=ref_query_groups, **kw)
                 prediction2d.append(anchor2d)
                 classification2d.append(cls2d)
                 prediction_alpha2d.append(alpha2d)
