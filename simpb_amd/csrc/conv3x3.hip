@@ -562,7 +562,8 @@ extern "C" int simpb_conv3x3_nhwc_f16(void* y, float* tokens, void* tokens_f16, 
     // they fill the chip (96 divides the pixel counts of a 6-camera rig and leaves no nearly empty last round of
     // workgroups), then the direct ones, K split inside the workgroup for the smallest maps
     const long long t96 = (p_out + 95) / 96, t128 = (p_out + 127) / 128, t64 = (p_out + 63) / 64;
-    if (out_channels >= 128 && t96 * ((out_channels + 127) / 128) >= 160) variant = 8;
+    if (out_channels >= 128 && t128 * ((out_channels + 127) / 128) >= 2048) variant = 6;   // many rounds: the larger tile wins
+    else if (out_channels >= 128 && t96 * ((out_channels + 127) / 128) >= 160) variant = 8;
     else if (t96 * ny >= 256) variant = 7;
     else if (t128 * ny >= 128) variant = 1;
     else if (t64 * ny >= 128) variant = 4;
