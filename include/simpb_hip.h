@@ -185,6 +185,14 @@ int simpb_format_tokens(float* col_feats, const void* const* level_ptrs, const v
 int simpb_bias_act_nhwc_f16(void* y, const void* bias, const void* residual, long long num_pixels, int channels,
                             int relu, void* stream);
 
+/* Stem epilogue of the BN-folded ResNet (mmdet ResNet.forward: conv1 -> bn1 -> relu -> maxpool(3, stride 2, padding 1)):
+ *   y[n, oy, ox, c] = relu( max over the window of x[n, 2*oy-1+dy, 2*ox-1+dx, c] + bias[c] ),  dy, dx in 0..2 (inside the map)
+ * x f16 [num_images, in_h, in_w, channels] = the raw output of the 7x7 convolution (NHWC), y f16 [num_images, ho, wo, channels],
+ * ho = (in_h - 1) / 2 + 1. Bias and ReLU commute with the maximum, so this equals the bias/ReLU pass followed by the pooling
+ * kernel bit for bit, in one pass. channels % 8 == 0; 16-byte aligned. */
+int simpb_bias_relu_maxpool_nhwc_f16(void* y, const void* x, const void* bias, int num_images, int in_h, int in_w,
+                                     int channels, void* stream);
+
 /* A whole BN-folded 1x1 convolution of the fp16 channels_last backbone in one launch:
  *   y[n, ho, wo, :] = relu?( x[n, ho*stride, wo*stride, :] . weight^T + bias (+ residual[n, ho, wo, :]) )
  * x f16 [num_images, in_h, in_w, in_channels] (NHWC), weight f16 [out_channels, in_channels], bias f16 [out_channels],

@@ -26,6 +26,7 @@ SIGNATURES = {
     "simpb_gemm_f32": ([_P, _P], _I),
     "simpb_layernorm_f32": ([_P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P], _I),
     "simpb_bias_act_nhwc_f16": ([_P, _P, _P, ctypes.c_longlong, _I, _I, _P], _I),
+    "simpb_bias_relu_maxpool_nhwc_f16": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "simpb_conv1x1_nhwc_f16": ([_P] * 5 + [_I] * 8 + [_P, _I, _P], _I),
     "simpb_conv3x3_nhwc_f16": ([_P, _P, _P, _I, _I, _P, _P, _P] + [_I] * 8 + [_P], _I),
     "simpb_linear_f16in_split": ([_P] * 5 + [_I] * 3 + [_P], _I),

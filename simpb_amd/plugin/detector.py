@@ -24,6 +24,8 @@ CONV1X1_KERNEL = True
 # included; the FPN's write the decoder's fp32 tokens themselves); False: vendor convolution (+ csrc/bias_act.hip / the
 # token format pass), also the cross-check in tests.
 CONV3X3_KERNEL = True
+# True: the stem's bias + ReLU + 3x3/2 max-pool as one pass (csrc/bias_act.hip); False: csrc/bias_act.hip + PyTorch's pooling
+STEM_EPILOGUE_KERNEL = True
 
 
 class Bottleneck(nn.Module):
@@ -122,10 +124,14 @@ class ResNet(BaseModule):
 
     def forward(self, x):
         if getattr(self, "fused_epilogue", False) and x.is_cuda and x.dtype == torch.float16:
-            from .ops import bias_act_
-            x = bias_act_(F.conv2d(x, self.conv1.weight, None, self.conv1.stride, self.conv1.padding), self.conv1.bias,
-                          None, relu=True)
-            x = self.maxpool(x)
+            from .ops import bias_act_, bias_relu_maxpool
+            x = F.conv2d(x, self.conv1.weight, None, self.conv1.stride, self.conv1.padding)
+            mp = self.maxpool
+            if (STEM_EPILOGUE_KERNEL and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1 and mp.dilation == 1
+                    and not mp.ceil_mode and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)):
+                x = bias_relu_maxpool(x, self.conv1.bias)   # bias + ReLU + max-pool in one pass (bit-equal to the two)
+            else:
+                x = self.maxpool(bias_act_(x, self.conv1.bias, None, relu=True))
         else:
             x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         outs = []

@@ -340,6 +340,21 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
+def bias_relu_maxpool(x, bias):
+    """maxpool3x3/2(relu(x + bias[c])) for a channels_last f16 tensor [N, C, H, W] in one pass (csrc/bias_act.hip): the
+    stem epilogue of the BN-folded ResNet (conv1 -> bn1 -> relu -> maxpool)."""
+    _require_gpu(x, bias)
+    n, c, h, w = x.shape
+    if (x.dtype != torch.float16 or not x.is_contiguous(memory_format=torch.channels_last) or bias.dtype != torch.float16
+            or bias.numel() != c or c % 8 or not bias.is_contiguous()):
+        raise ValueError("bias_relu_maxpool takes a channels_last f16 tensor and an f16 bias with channels % 8 == 0")
+    y = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), device=x.device, dtype=torch.float16,
+                    memory_format=torch.channels_last)
+    _lib.check(_lib.lib().simpb_bias_relu_maxpool_nhwc_f16(_ptr(y), _ptr(x), _ptr(bias), n, h, w, c, _stream()),
+               "simpb_bias_relu_maxpool_nhwc_f16")
+    return y
+
+
 def conv1x1_nhwc(x, weight, bias, residual=None, relu=True, stride=1, residual_upsample2x=False, input_bias=None, variant=0):
     """relu?(conv1x1(x, weight, stride) + bias + residual?) for a channels_last f16 tensor, one launch
     (csrc/conv1x1.hip). x [N, Cin, H, W]; weight [Cout, Cin, 1, 1] f16; bias f16 [Cout]. With residual_upsample2x the

@@ -509,6 +509,21 @@ def test_conv1x1_kernel_vs_conv2d(cin, cout, h, w, stride, res, relu, variant):
 
 
 @gpu
+@pytest.mark.parametrize("n,c,h,w", [(6, 64, 128, 352), (2, 64, 7, 9), (1, 16, 1, 1), (3, 24, 6, 5)])
+def test_stem_epilogue_equals_bias_relu_then_maxpool(n, c, h, w):
+    """csrc/bias_act.hip: bias + ReLU + max_pool2d(3, stride 2, padding 1) in one pass against the two-pass route (mmdet
+    ResNet.forward: relu(bn1(conv1(x))) -> maxpool, BN folded): bit-equal, odd sizes and 1x1 maps included."""
+    from simpb_amd.plugin.ops import bias_act_, bias_relu_maxpool
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = torch.randn(n, c, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(c, generator=g).half().cuda()
+    want = F.max_pool2d(bias_act_(x.clone(), b, None, relu=True), 3, 2, 1)
+    got = bias_relu_maxpool(x, b)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+
+
+@gpu
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("cin,cout,h,w,stride,relu", [
     (64, 64, 64, 176, 1, True),       # layer1 conv2
