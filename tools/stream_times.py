@@ -16,9 +16,13 @@ model = plugin.build_detector(cfg["model"]).eval()
 synth.load_procedural(model)
 model = model.cuda().fuse_conv_bn().half_backbone()
 torch.backends.cudnn.benchmark = True
+if "--prio" in sys.argv:   # --prio BB HEAD: stream priorities of the backbone / decoder streams (default 0 -1: decoder first)
+    i = sys.argv.index("--prio")
+    PipelinedRunner.STREAM_PRIORITIES = (int(sys.argv[i + 1]), int(sys.argv[i + 2]))
+    print("stream priorities (backbone, decoder):", PipelinedRunner.STREAM_PRIORITIES, torch.cuda.Stream.priority_range(), flush=True)
 r = PipelinedRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"))
 DEC_ONLY = "--dec-only" in sys.argv   # for rocprofv3 --kernel-trace: decoder graph replays with nothing beside them
-if len(sys.argv) > 1 and not DEC_ONLY and "--co" not in sys.argv:
+if len(sys.argv) > 1 and not DEC_ONLY and "--co" not in sys.argv and "--prio" not in sys.argv:
     # --bb-drop N: the backbone stream loses one group of 8 CUs in every N groups (in every XCD, whichever way CU indices
     # map to XCDs); the decoder stream keeps the whole chip
     import ctypes
