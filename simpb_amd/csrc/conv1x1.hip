@@ -12,7 +12,9 @@
 // tiles of v_mfma_f32_32x32x16_f16; K in chunks of 64 through LDS (rows of 128 B staged as 16-byte pieces, two
 // chunks in flight in registers, unconditional clamped loads). The accumulator tile goes through LDS once so that
 // the residual is read and y is written in 16-byte pieces of full 128-byte rows. `stride` (1 or 2) subsamples
-// the input pixels (the downsample branches of stages 2-4).
+// the input pixels (the downsample branches of stages 2-4). Long-K layers (Cin >= 512) are forwarded to the staged
+// pipeline of csrc/conv3x3.hip with one tap (double-buffered stage, one barrier per chunk, XCD-ordered tiles), where
+// it measured faster (tools/bench_conv1x1.py); this kernel keeps the short ones and the input-side epilogue.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <type_traits>

@@ -12,7 +12,9 @@ runs eagerly too (lazy initialisation outside the capture), the second is captur
 query set ever exceeds the capacity, the overflow flags (read back with the records) trigger an eager
 rerun of that frame with a larger capacity: the frame-end commit of the instance bank holds back when
 a flag is set (csrc/bank.hip `hold`), so the rerun starts from the state the frame found, the graphs
-are re-captured at the new capacity, and results never silently degrade.
+are re-captured at the new capacity, and results never silently degrade. PipelinedRunner enqueues every
+decoder one step early (before the previous frame's flags have reached the host) and therefore chains the
+hold on the device: see its docstring.
 """
 import numpy as np
 import torch
