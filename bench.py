@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="do not replay the frame as a hipGraph")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap backbone(t+1) with decoder(t) (simpb_amd.runner.PipelinedRunner)")
+    ap.add_argument("--no-split", action="store_true",
+                    help="keep the single-frame decoder layer of frame t+1 behind the temporal part of frame t "
+                         "(simpb_amd.runner.PipelinedRunner instead of SplitPipelinedRunner)")
     ap.add_argument("--meter-frames", type=int, default=8, help="instrumented eager frames for the roofline leg")
     ap.add_argument("--no-conv-search", action="store_true",
                     help="do not let MIOpen benchmark convolution algorithms during warm-up (cudnn.benchmark off)")
@@ -213,7 +216,7 @@ def main():
     torch.set_num_threads(max(1, min(4, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
 
     from simpb_amd.dist import DetectionGather
-    from simpb_amd.runner import FrameRunner, PipelinedRunner
+    from simpb_amd.runner import FrameRunner, PipelinedRunner, SplitPipelinedRunner
     torch.backends.cudnn.benchmark = not args.no_conv_search
     total = args.prime + args.warmup + args.steps + args.meter_frames
     imgs = make_frames(args, device, total)
@@ -229,7 +232,7 @@ def main():
     runners = []
     for _ in range(args.streams):  # one model replica + runner per independent stream
         model = build_model(args, device)
-        runners.append((PipelinedRunner if pipelined else FrameRunner)(
+        runners.append(((PipelinedRunner if args.no_split else SplitPipelinedRunner) if pipelined else FrameRunner)(
             model, args.bs, (args.image_wh[1], args.image_wh[0]), capacity=args.capacity, device=device,
             use_graph=not args.eager))
     runner = runners[0]

@@ -219,6 +219,24 @@ class SimPBHead(BaseModule):
 
     # ------------------------------------------------------------------ forward
     def forward(self, feature_maps, metas: dict):
+        """simpb_head.py:323-747 (inference)."""
+        gen = self._forward(feature_maps, metas, split=False)
+        try:
+            next(gen)
+        except StopIteration as done:
+            return done.value
+        raise RuntimeError("unsplit forward does not pause")
+
+    def forward_split(self, feature_maps, metas: dict):
+        """The same forward as a two-step generator, for callers that overlap frames (runner.SplitPipelinedRunner):
+        `next(gen)` runs the single-frame decoder layer(s) -- everything up to the first InstanceBank.update
+        (simpb_head.py:690-696), which reads nothing the previous frame's decoder wrote (learned anchors only; the time
+        step comes in as metas["time_interval"]) -- and pauses; `gen.send(None)` runs the temporal rest (bank.get,
+        update, the remaining layers, cache) and ends with StopIteration carrying the output dict. Same launches, same
+        numbers as forward() except that the two anchor sets are embedded by two encoder launches instead of one."""
+        return self._forward(feature_maps, metas, split=True)
+
+    def _forward(self, feature_maps, metas: dict, split: bool):
         if self.training:
             raise NotImplementedError("SimPBHead here is the inference path; training (denoising, losses) is out of scope")
         if isinstance(feature_maps, torch.Tensor):
@@ -227,8 +245,15 @@ class SimPBHead(BaseModule):
         if self.sampler is not None and self.sampler.dn_metas is not None:
             self.sampler.dn_metas = None  # :333-334; never set in eval
 
-        instance_feature, anchor, temp_instance_feature, temp_anchor, time_interval = self.instance_bank.get(
-            batch_size, metas, dn_metas=None)
+        if split:
+            if "time_interval" not in metas or self.static_capacity is None:
+                raise ValueError("forward_split needs metas['time_interval'] (f32 [bs]) and a static capacity")
+            instance_feature, anchor = self.instance_bank.learned(batch_size)
+            temp_instance_feature = temp_anchor = None
+            time_interval = metas["time_interval"]
+        else:
+            instance_feature, anchor, temp_instance_feature, temp_anchor, time_interval = self.instance_bank.get(
+                batch_size, metas, dn_metas=None)
         if temp_anchor is not None and anchor.is_cuda:
             # one encoder launch over both anchor sets (the chain kernel is latency-bound per launch)
             both = self.anchor_encoder.forward(torch.cat([anchor, temp_anchor], dim=1))
@@ -256,7 +281,18 @@ class SimPBHead(BaseModule):
         if cap is not None:
             n_alloc = sum(op == "allocation" for op in self.operation_order)
             chain = metas.get("overflow_chain")
-            if chain is not None:
+            sticky = None
+            if split:
+                # (hb i32 [n_alloc + 1] owned by the caller, sticky i32 [1]): this frame's flags live in hb[:n_alloc]; the
+                # last entry receives, when the temporal part starts, the `sticky` word the frame decoded before this one
+                # left (1 = that frame held its commit back), and this frame leaves max(hb) in `sticky` in turn
+                hb, sticky = metas["overflow_split"]
+                if hb.dtype != torch.int32 or hb.numel() != n_alloc + 1 or sticky.dtype != torch.int32 or sticky.numel() != 1:
+                    raise ValueError("overflow_split: (i32 [allocation layers + 1], i32 [1])")
+                overflow = hb[:n_alloc]
+                overflow.zero_()
+                hold = hb
+            elif chain is not None:
                 # (flags i32 [rows, n_alloc] owned by the caller, this frame's row): the commit also holds back when a flag
                 # of the OTHER rows is set, i.e. when the frame decoded just before this one (enqueued while its own flags
                 # had not reached the host yet: runner.PipelinedRunner) is going to be re-run
@@ -344,6 +380,13 @@ class SimPBHead(BaseModule):
                 classification.append(cls)
                 quality.append(qt)
                 if len(prediction) == self.num_single_frame_decoder:
+                    if split:
+                        yield "single-frame layers done"
+                        # ---- the temporal part: needs what the previous frame's decoder committed
+                        _, _, temp_instance_feature, temp_anchor, time_interval = self.instance_bank.get(
+                            batch_size, metas, dn_metas=None)
+                        temp_anchor_embed = self.anchor_encoder(temp_anchor) if temp_anchor is not None else None
+                        hold[-1:].copy_(sticky)
                     instance_feature, anchor = self.instance_bank.update(instance_feature, anchor, cls)
                 if i != last:
                     anchor_embed = self.anchor_encoder(anchor)
@@ -365,6 +408,8 @@ class SimPBHead(BaseModule):
         if ids is None:
             self.instance_bank.cache(instance_feature, anchor, cls, metas, feature_maps)
             ids = self.instance_bank.get_instance_id(cls, anchor, self.decoder.score_threshold)
+        if split:
+            torch.amax(hold, dim=0, keepdim=True, out=sticky)   # what the next frame's commit has to respect
         output["instance_id"] = ids
         return output
 

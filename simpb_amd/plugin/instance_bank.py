@@ -124,6 +124,11 @@ class InstanceBank(nn.Module):
             return stored_anchor
         return self.anchor_handler.anchor_projection(stored_anchor, [T_temp2cur], time_intervals=[-dt])[0]
 
+    def learned(self, batch_size):
+        """(feature, anchor) of the learned tables alone (instance_bank.py:81-82): what the single-frame decoder layer
+        starts from; touches no temporal state."""
+        return self.instance_feature[None].expand(batch_size, -1, -1), self.anchor[None].expand(batch_size, -1, -1)
+
     def get(self, batch_size, metas=None, dn_metas=None):
         """instance_bank.py:79-119 -> (feature, anchor, cached feature, cached anchor, time step).
         The learned tables are expanded, not tiled: they are read-only downstream."""

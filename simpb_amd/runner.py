@@ -330,13 +330,12 @@ class PipelinedRunner(FrameRunner):
             # larger slot array (the graphs are re-captured at the new capacity afterwards)
             behind = list(self.queue)
             self.queue.clear()
-            self.s_head.synchronize()
-            with torch.cuda.stream(self.s_head):
-                self.flags.zero_()   # the speculative decoder behind may have left flags of its own: the re-runs start clean
+            self._quiesce()
             while bool(h[2].any()):
                 self._grow()
                 if not job["warm"]:
                     self.head.instance_bank.reset()  # a cold frame starts from an empty bank again
+                self._clear_hold()   # flags left by the overflowed attempt / the speculative decoder behind it
                 job = self._enqueue_decoder(job["slot"], job["metas"], job["prev"], True)
                 job["done"].synchronize()
                 h = self.host[job["slot"]]
@@ -346,6 +345,13 @@ class PipelinedRunner(FrameRunner):
         self.prev_metas = dict(img_metas=job["metas"]["img_metas"])
         results = SparseBox3DDecoder.decode_static_host(h[0].numpy(), h[1].numpy(), self.head.num_cams)
         return [{"img_bbox": r} for r in results]
+
+    def _quiesce(self):
+        self.s_head.synchronize()
+
+    def _clear_hold(self):
+        with torch.cuda.stream(self.s_head):
+            self.flags.zero_()
 
     def collect(self):
         """Returns the detections of frame t-1 (None the first time): waits for the decoder enqueued one step ago,
@@ -366,3 +372,151 @@ class PipelinedRunner(FrameRunner):
         while self.queue:
             out = self._finish(self.queue.pop(0))
         return out
+
+
+class SplitPipelinedRunner(PipelinedRunner):
+    """PipelinedRunner with the single-frame decoder layer taken off the temporal chain.
+
+    Frame t's decoder needs the bank frame t-1 committed -- but not from its first instruction: the first decoder layer
+    (`num_single_frame_decoder`, simpb_head.py:690-696: allocation, the 2D block, aggregation, the first refinement) starts
+    from the learned anchors alone, and the bank enters with InstanceBank.update behind it. SimPBHead.forward_split pauses
+    there. This runner replays that first part ("A", ~1/6 of the decoder) on a third stream as soon as backbone(t) is done,
+    beside the temporal part ("B") of frame t-1; B(t) then waits for A(t) (an event) and B(t-1) (stream order). The chain
+    of dependent launches a frame adds to the critical path shrinks by A.
+
+    What changes with A(t) running while B(t-1) is still in flight:
+      * per-frame decoder inputs (projection matrices, ego-motion, time step) get one device buffer per feature slot;
+      * the overflow hold is chained through a `sticky` word that B writes at its end (A(t+1) must not be able to disturb
+        the flags B(t) looks at): SimPBHead.forward_split, `overflow_split`;
+      * eager (warm-up, re-run) frames run A and B back to back on the decoder stream: only replayed graphs use the third
+        stream, so no tensor of the caching allocator crosses streams.
+    """
+
+    def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True):
+        super().__init__(model, batch_size, image_hw, capacity, device, use_graph)
+        dev = self.device
+        self.s_pre = torch.cuda.Stream(device=dev, priority=getattr(self, "STREAM_PRIORITIES", (0, -1))[1])
+        n_alloc = self.flags.shape[1]
+        self.hb = torch.zeros(2, n_alloc + 1, dtype=torch.int32, device=dev)   # per slot: the frame's flags | sticky copy
+        self.sticky = torch.zeros(1, dtype=torch.int32, device=dev)
+        cams = self.head.num_cams
+        self.proj2 = [torch.zeros(batch_size, cams, 4, 4, device=dev) for _ in range(2)]
+        self.t_buf2 = [torch.zeros(batch_size, 4, 4, device=dev) for _ in range(2)]
+        self.dt_buf2 = [torch.zeros(batch_size, device=dev) for _ in range(2)]
+        self.ti_buf2 = [torch.zeros(batch_size, device=dev) for _ in range(2)]
+        self.pin2 = [dict(proj=torch.zeros(batch_size, cams, 4, 4).pin_memory(), t=torch.zeros(batch_size, 4, 4).pin_memory(),
+                          dt=torch.zeros(batch_size).pin_memory(), ti=torch.zeros(batch_size).pin_memory()) for _ in range(2)]
+        self.staged2 = [None, None]
+        self.pre_graph = [None, None]
+        self.pre_done = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def _drop_graphs(self):
+        super()._drop_graphs()
+        self.pre_graph = [None, None]
+
+    def _stage_slot(self, slot, metas, prev, stream):
+        """Per-frame decoder inputs of the frame in `slot`, into that slot's own device buffers."""
+        if self.staged2[slot] is not None:
+            self.staged2[slot].synchronize()
+        pin = self.pin2[slot]
+        bank = self.head.instance_bank
+        pin["proj"].copy_(metas["projection_mat"] if not metas["projection_mat"].is_cuda else metas["projection_mat"].cpu())
+        pin["ti"].fill_(float(bank.default_time_interval))
+        if prev is not None:
+            for i, m in enumerate(metas["img_metas"]):
+                t = m["T_global_inv"] @ prev["img_metas"][i]["T_global"]
+                pin["t"][i] = torch.from_numpy(np.asarray(t, np.float32))
+                pin["dt"][i] = float(m["timestamp"] - prev["img_metas"][i]["timestamp"])
+            # the time step the refinement heads divide by (instance_bank.py:108-113, csrc/bank.hip bank_get_kernel): the
+            # frame gap where it is usable, the default otherwise -- a function of the time stamps alone, in f32 like there
+            dt32 = pin["dt"].numpy()
+            ok = (dt32 != 0) & (np.abs(dt32) <= np.float32(bank.max_time_interval))
+            pin["ti"].copy_(torch.from_numpy(np.where(ok, dt32, np.float32(bank.default_time_interval)).astype(np.float32)))
+        with torch.cuda.stream(stream):
+            self.proj2[slot].copy_(pin["proj"], non_blocking=True)
+            self.ti_buf2[slot].copy_(pin["ti"], non_blocking=True)
+            if prev is not None:
+                self.t_buf2[slot].copy_(pin["t"], non_blocking=True)
+                self.dt_buf2[slot].copy_(pin["dt"], non_blocking=True)
+            self.staged2[slot] = torch.cuda.Event()
+            self.staged2[slot].record(stream)
+
+    def _split_metas(self, metas, slot, warm):
+        out = dict(projection_mat=self.proj2[slot], image_wh=self.wh, image_wh_host=self.wh_host, img_metas=metas["img_metas"],
+                   time_interval=self.ti_buf2[slot], overflow_split=(self.hb[slot], self.sticky))
+        if warm:
+            out["bank_inputs"] = (self.t_buf2[slot], self.dt_buf2[slot])
+        return out
+
+    def _part_a(self, slot, dmetas):
+        gen = self.head.forward_split(self.fm[slot], dmetas)
+        next(gen)
+        return gen
+
+    def _part_b(self, gen, aug):
+        try:
+            gen.send(None)
+        except StopIteration as done:
+            outs = done.value
+        else:
+            raise RuntimeError("forward_split paused twice")
+        alloc = outs["alloc_list"][-1]
+        rec3d, rec2d = self.head.decoder.decode_static_device(
+            outs["classification"], outs["prediction"], outs["instance_id"], outs["quality"],
+            outs["classification2d"], outs["prediction2d"], alloc, aug)
+        return rec3d, rec2d, outs["overflow"]
+
+    def _enqueue_decoder(self, slot, metas, prev, force_eager):
+        warm = prev is not None
+        self.prev_metas = prev
+        aug = metas["img_metas"][0]["aug_config"]
+        dmetas = self._split_metas(metas, slot, warm)
+        graph_ok = (self.use_graph and not force_eager and warm and self.bb_graph[slot] is not None
+                    and self.fm[slot] is self.bb_out[slot])
+        if graph_ok and self.head_graph[slot] is None and self.head_runs[slot] >= 1:
+            # capture A and B of this slot (both on the decoder stream; A is replayed on the third stream afterwards)
+            self.s_pre.synchronize()
+            self.s_head.synchronize()
+            self._stage_slot(slot, metas, prev, self.s_head)
+            with torch.cuda.stream(self.s_head):
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, stream=self.s_head):
+                    gen = self._part_a(slot, dmetas)
+                with torch.cuda.graph(gb, stream=self.s_head, pool=ga.pool()):
+                    self.head_out[slot] = self._part_b(gen, aug)
+                del gen
+            self.pre_graph[slot], self.head_graph[slot] = ga, gb
+        if graph_ok and self.head_graph[slot] is not None:
+            self._stage_slot(slot, metas, prev, self.s_pre)
+            with torch.cuda.stream(self.s_pre):
+                self.s_pre.wait_event(self.bb_done[slot])
+                self.pre_graph[slot].replay()
+                self.pre_done[slot].record(self.s_pre)
+            with torch.cuda.stream(self.s_head):
+                self.s_head.wait_event(self.pre_done[slot])
+                if self.rec_consumed is not None:
+                    self.s_head.wait_event(self.rec_consumed)
+                self.head_graph[slot].replay()
+            rec = self.head_out[slot]
+            self.stats["replay"] += 1
+        else:
+            self.s_head.wait_stream(self.s_pre)   # a replayed A of the other slot may still be running: eager frames go after it
+            self._stage_slot(slot, metas, prev, self.s_head)
+            with torch.cuda.stream(self.s_head):
+                rec = self._part_b(self._part_a(slot, dmetas), aug)
+            self.stats["eager"] += 1
+            if graph_ok:
+                self.head_runs[slot] += 1
+        done = self._enqueue_readback(slot, rec)
+        return dict(slot=slot, metas=metas, prev=prev, warm=warm, rec=rec, done=done)
+
+    def _quiesce(self):
+        self.s_pre.synchronize()
+        self.s_head.synchronize()
+
+    def _clear_hold(self):
+        # an overflowed attempt leaves its flags and sticky = 1 (so does the speculative decoder behind it): every re-run
+        # starts clean
+        with torch.cuda.stream(self.s_head):
+            self.sticky.zero_()
+            self.hb.zero_()

@@ -129,21 +129,24 @@ class _StagedModel(torch.nn.Module):
         return self.bufs[key]
 
 
-def _golden_pipelined_runner(spec):
-    from simpb_amd.runner import PipelinedRunner
+def _golden_pipelined_runner(spec, split=False):
+    from simpb_amd.runner import PipelinedRunner, SplitPipelinedRunner
     model = _StagedModel(build_product_head(spec), spec)
     w, h = spec["image_wh"]
-    runner = PipelinedRunner(model, 1, (8, 8), capacity=1536, device=torch.device("cuda"), use_graph=True)
+    runner = (SplitPipelinedRunner if split else PipelinedRunner)(model, 1, (8, 8), capacity=1536, device=torch.device("cuda"),
+                                                                  use_graph=True)
     runner.wh = torch.tensor([float(w), float(h)], device="cuda").view(1, 1, 2).repeat(1, 6, 1)
     runner.wh_host = (w, h)
     return model, runner
 
 
-def test_pipelined_runner_vs_golden():
-    """Backbone(t+1) overlapped with decoder(t): same detections, one step later."""
+@pytest.mark.parametrize("split", [False, True])
+def test_pipelined_runner_vs_golden(split):
+    """Backbone(t+1) overlapped with decoder(t): same detections, one step later. split: the single-frame decoder layer of
+    frame t+1 additionally runs beside the temporal part of frame t (runner.SplitPipelinedRunner, SimPBHead.forward_split)."""
     g = load_golden("head_r50.npz")
     spec = spec_of(g)
-    model, runner = _golden_pipelined_runner(spec)
+    model, runner = _golden_pipelined_runner(spec, split)
     outs = []
     for f in range(spec["frames"]):
         model.stage(f)
@@ -155,12 +158,13 @@ def test_pipelined_runner_vs_golden():
         compare_result(outs[f + 1][0]["img_bbox"], g, f"f{f}.res0.")
 
 
-def test_pipelined_runner_overflow_reruns_the_decoder():
+@pytest.mark.parametrize("split", [False, True])
+def test_pipelined_runner_overflow_reruns_the_decoder(split):
     """Same stream through the pipelined runner with a slot array that is too small: the decoder of the overflowed
     frame is re-run (beside the next frame's backbone) and the golden detections come out, one step later."""
     g = load_golden("head_r50.npz")
     spec = spec_of(g)
-    model, runner = _golden_pipelined_runner(spec)
+    model, runner = _golden_pipelined_runner(spec, split)
     runner.capacity = runner.head.static_capacity = 768
     outs = []
     for f in range(spec["frames"]):
@@ -173,14 +177,15 @@ def test_pipelined_runner_overflow_reruns_the_decoder():
     assert runner.stats["overflow"] >= 1 and runner.capacity > 768, (runner.stats, runner.capacity)
 
 
-def test_pipelined_runner_overflow_with_a_decoder_already_enqueued_behind():
+@pytest.mark.parametrize("split", [False, True])
+def test_pipelined_runner_overflow_with_a_decoder_already_enqueued_behind(split):
     """Overflow in the middle of a warm stream of the pipelined runner: the slot array is shrunk before frame 1 is fed,
     so decoder(1) overflows with a warm bank WHILE decoder(2) has already been enqueued behind it (the host had not seen
     the flags yet). The bank commit of both holds back on the device (overflow_chain), both are re-run in order at a
     grown capacity, and the stream's detections and track ids are the golden ones."""
     g = load_golden("head_r50.npz")
     spec = spec_of(g)
-    model, runner = _golden_pipelined_runner(spec)
+    model, runner = _golden_pipelined_runner(spec, split)
     outs = []
     for f in range(spec["frames"]):
         if f == 1:
@@ -195,6 +200,8 @@ def test_pipelined_runner_overflow_with_a_decoder_already_enqueued_behind():
         compare_result(outs[f + 1][0]["img_bbox"], g, f"f{f}.res0.")
     assert runner.stats["overflow"] >= 1 and runner.capacity > 640, (runner.stats, runner.capacity)
     assert int(runner.flags.abs().sum()) == 0
+    if split:
+        assert int(runner.sticky.item()) == 0 and int(runner.hb.abs().sum()) == 0
 
 
 def test_config3_eight_streams_per_gpu_vs_golden():
@@ -298,6 +305,7 @@ def test_pipelined_equals_plain_runner_with_real_backbone():
             out = []
             for f in range(frames):
                 out.append(r.step(src[f], metas[f]))
+                r.s_bb.synchronize()  # (the test reads the runner's buffers from another stream; step() does not wait for backbone(f))
                 assert torch.equal(r.imgs[f % 2].cpu(), imgs[f].cpu()), (name, f)  # the frame the backbone just read
                 if f >= 1:  # the maps decoder(f-1) just read; backbone(f) wrote the other slot meanwhile
                     seen.append(snapshot(r.fm[(f - 1) % 2]))
@@ -366,6 +374,7 @@ def test_two_pipelined_runners_side_by_side():
             if f >= 1:
                 seen[i].append([t.clone() for t in list(runners[i].fm[(f - 1) % 2])[:3]])
     for i in range(2):
+        runners[i].s_bb.synchronize()  # (reading the runner's feature slot from this stream: collect() does not wait for the backbone)
         seen[i].append([t.clone() for t in list(runners[i].fm[(frames - 1) % 2])[:3]])
         out = outs[i][1:] + [runners[i].flush()]
         assert runners[i].stats["replay"] >= 4, runners[i].stats
