@@ -229,10 +229,13 @@ def main():
     pipelined = not args.no_pipeline and not args.eager
     if args.streams > 1 and not pipelined:
         raise SystemExit("--streams needs the pipelined runner")
+    # the third stream pays off when ONE stream's chain of dependent launches bounds the frame (347 vs 335 frames/s); with
+    # several streams or a batch the chip is busy anyway and the extra launches cost (8 streams: 308 vs 394 per GPU)
+    split = pipelined and not args.no_split and args.streams == 1 and args.bs == 1
     runners = []
     for _ in range(args.streams):  # one model replica + runner per independent stream
         model = build_model(args, device)
-        runners.append(((PipelinedRunner if args.no_split else SplitPipelinedRunner) if pipelined else FrameRunner)(
+        runners.append(((SplitPipelinedRunner if split else PipelinedRunner) if pipelined else FrameRunner)(
             model, args.bs, (args.image_wh[1], args.image_wh[0]), capacity=args.capacity, device=device,
             use_graph=not args.eager))
     runner = runners[0]
@@ -296,7 +299,7 @@ def main():
         head0 = runner.head
         n2 = [int(x) for x in head0.layers[0].last.count.sum(dim=1).tolist()] if head0.layers[0].last else None
         mode = dict(runner.stats, hipgraph=not args.eager, capacity_2d=args.capacity,
-                    pipelined_backbone=pipelined)
+                    pipelined_backbone=pipelined, single_frame_layer_on_third_stream=split)
         def pmc_traffic(kernel):
             """HBM-side bytes per launch of `kernel` from the newest committed PMC passes (profiles/r*_sampler_traffic.json;
             rocprofv3 --pmc cannot run inside this process: tools/profile_round.py takes them with this same command),

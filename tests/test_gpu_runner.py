@@ -204,7 +204,8 @@ def test_pipelined_runner_overflow_with_a_decoder_already_enqueued_behind(split)
         assert int(runner.sticky.item()) == 0 and int(runner.hb.abs().sum()) == 0
 
 
-def test_config3_eight_streams_per_gpu_vs_golden():
+@pytest.mark.parametrize("split", [False, True])
+def test_config3_eight_streams_per_gpu_vs_golden(split):
     """BASELINE config #3 shape on one GPU: 8 independent camera streams at R50 704x256, each its own pipelined runner
     (bs = 1, the reference's own test setting), launched back to back and collected together like bench.py --streams 8.
     Every stream is fed the golden feature stream (stream i starts i % 3 steps late, so neighbours are at different
@@ -215,7 +216,7 @@ def test_config3_eight_streams_per_gpu_vs_golden():
     g = load_golden("head_r50.npz")
     spec = spec_of(g)
     n, frames = 8, spec["frames"]
-    pairs = [_golden_pipelined_runner(spec) for _ in range(n)]
+    pairs = [_golden_pipelined_runner(spec, split) for _ in range(n)]
     lag = [i % 3 for i in range(n)]
     gather = DetectionGather(n, 300, torch.device("cuda"))
     outs = [[] for _ in range(n)]
@@ -278,7 +279,7 @@ def test_pipelined_equals_plain_runner_with_real_backbone():
     saw them and served again to the plain eager runner: a stale slot, a decoder that started before its
     backbone finished or a backbone that overwrote maps still in use would all show as a difference."""
     from simpb_amd import configs, plugin
-    from simpb_amd.runner import FrameRunner, PipelinedRunner
+    from simpb_amd.runner import FrameRunner, PipelinedRunner, SplitPipelinedRunner
     wh = (352, 128)
 
     def make():
@@ -294,14 +295,15 @@ def test_pipelined_equals_plain_runner_with_real_backbone():
     def snapshot(fm):
         return [t.clone() for t in list(fm)[:3]]
 
-    for name in ("graph", "pipe", "pipe_h2d"):
+    for name in ("graph", "pipe", "pipe_h2d", "pipe_split"):   # pipe_split: + the single-frame decoder layer on a third stream
         model = make()
         seen = []
         if name.startswith("pipe"):
-            r = PipelinedRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=True)
+            cls = SplitPipelinedRunner if name == "pipe_split" else PipelinedRunner
+            r = cls(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=True)
             # pipe_h2d: frames handed over in pinned host memory, copied inside the step on the backbone stream
             # beside the previous frame's decoder (bench.py --h2d)
-            src = imgs if name == "pipe" else [x.cpu().pin_memory() for x in imgs]
+            src = imgs if name != "pipe_h2d" else [x.cpu().pin_memory() for x in imgs]
             out = []
             for f in range(frames):
                 out.append(r.step(src[f], metas[f]))
