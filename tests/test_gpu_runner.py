@@ -204,6 +204,33 @@ def test_pipelined_runner_overflow_with_a_decoder_already_enqueued_behind(split)
         assert int(runner.sticky.item()) == 0 and int(runner.hb.abs().sum()) == 0
 
 
+def test_split_runner_equals_two_stream_runner_bit_for_bit():
+    """40 frames of synthetic features through PipelinedRunner and SplitPipelinedRunner (graphs, three streams, part A of
+    frame t beside part B of frame t-1): the same launches on the same numbers, so every detection, score and track id must
+    be IDENTICAL, frame by frame -- a stale staging buffer, a flag row touched by the wrong frame or a part B that started
+    before its part A would show here."""
+    g = load_golden("head_r50.npz")
+    spec = spec_of(g)
+    frames = 40
+    outs = {}
+    for split in (False, True):
+        model, runner = _golden_pipelined_runner(spec, split)
+        res = []
+        for f in range(frames):
+            model.stage(f)
+            torch.cuda.synchronize()
+            res.append(runner.step(runner.img, synth.frame_metas(1, f, spec["image_wh"])))
+        res.append(runner.flush())
+        assert runner.stats["replay"] >= frames - 10 and runner.stats["overflow"] == 0, runner.stats
+        outs[split] = res[1:]
+    for f, (a, b) in enumerate(zip(outs[False], outs[True])):
+        a, b = a[0]["img_bbox"], b[0]["img_bbox"]
+        assert set(a) == set(b)
+        for k in a:
+            x, y = (torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v for v in (a[k], b[k]))
+            assert torch.equal(x.cpu(), y.cpu()), (f, k)
+
+
 @pytest.mark.parametrize("split", [False, True])
 def test_config3_eight_streams_per_gpu_vs_golden(split):
     """BASELINE config #3 shape on one GPU: 8 independent camera streams at R50 704x256, each its own pipelined runner
