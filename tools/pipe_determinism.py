@@ -54,6 +54,7 @@ def main():
                 out.append(r.step(imgs[f], metas[f]))
                 if f >= 1:
                     sums.append(checksum(r.fm[(f - 1) % 2]))
+            r.s_bb.synchronize()   # step() does not wait for the backbone of the frame just fed
             sums.append(checksum(r.fm[(frames - 1) % 2]))
             out = out[1:] + [r.flush()]
         else:

@@ -241,6 +241,7 @@ def main():
                     o.collect()
             if f >= 1:
                 seen.append([t.clone() for t in r.fm[(f - 1) % 2][:3]])
+        r.s_bb.synchronize()   # collect() does not wait for the backbone of the frame just fed
         seen.append([t.clone() for t in r.fm[(frames - 1) % 2][:3]])
         out = out[1:] + [r.flush()]
         lines = []
