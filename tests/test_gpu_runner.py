@@ -114,7 +114,7 @@ class _StagedModel(torch.nn.Module):
 
     def stage(self, f):
         from simpb_amd.plugin import ops
-        fresh = ops.feature_maps_format([x.cuda() for x in synth.feature_maps_nchw(1, f, self.spec["image_wh"])])[0]
+        fresh = ops.feature_maps_format([x.cuda() for x in synth.feature_maps_nchw(self.spec["bs"], f, self.spec["image_wh"])])[0]
         if self.staged is None:
             self.staged = torch.empty_like(fresh)
         self.staged.copy_(fresh)
@@ -124,18 +124,19 @@ class _StagedModel(torch.nn.Module):
         key = img.data_ptr()
         if key not in self.bufs:
             self.bufs[key] = ops.feature_maps_format(
-                [torch.zeros_like(x).cuda() for x in synth.feature_maps_nchw(1, 0, self.spec["image_wh"])])
+                [torch.zeros_like(x).cuda() for x in synth.feature_maps_nchw(self.spec["bs"], 0, self.spec["image_wh"])])
         self.bufs[key][0].copy_(self.staged, non_blocking=True)
         return self.bufs[key]
 
 
-def _golden_pipelined_runner(spec, split=False):
+def _golden_pipelined_runner(spec, split=False, capacity=1536):
     from simpb_amd.runner import PipelinedRunner, SplitPipelinedRunner
     model = _StagedModel(build_product_head(spec), spec)
     w, h = spec["image_wh"]
-    runner = (SplitPipelinedRunner if split else PipelinedRunner)(model, 1, (8, 8), capacity=1536, device=torch.device("cuda"),
-                                                                  use_graph=True)
-    runner.wh = torch.tensor([float(w), float(h)], device="cuda").view(1, 1, 2).repeat(1, 6, 1)
+    bs = spec["bs"]
+    runner = (SplitPipelinedRunner if split else PipelinedRunner)(model, bs, (8, 8), capacity=capacity,
+                                                                  device=torch.device("cuda"), use_graph=True)
+    runner.wh = torch.tensor([float(w), float(h)], device="cuda").view(1, 1, 2).repeat(bs, 6, 1)
     runner.wh_host = (w, h)
     return model, runner
 
@@ -156,6 +157,25 @@ def test_pipelined_runner_vs_golden(split):
     assert outs[0] is None
     for f in range(spec["frames"]):
         compare_result(outs[f + 1][0]["img_bbox"], g, f"f{f}.res0.")
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_pipelined_runner_batched_stream_with_a_time_gap(split):
+    """The small golden stream (bs = 2, one stream jumps in time: the bank's max_time_interval mask, instance_bank.py:87,
+    and the default time step in the refinement heads, :108-113) through both pipelined runners. In the split runner the
+    time step of the single-frame layer is derived on the host from the time stamps (runner._stage_slot)."""
+    g = load_golden("head_small.npz")
+    spec = spec_of(g)
+    model, runner = _golden_pipelined_runner(spec, split, capacity=96)
+    outs = []
+    for f in range(spec["frames"]):
+        model.stage(f)
+        torch.cuda.synchronize()
+        outs.append(runner.step(runner.img, synth.frame_metas(spec["bs"], f, spec["image_wh"], jump=spec["jump"])))
+    outs.append(runner.flush())
+    for f in range(spec["frames"]):
+        for b in range(spec["bs"]):
+            compare_result(outs[f + 1][b]["img_bbox"], g, f"f{f}.res{b}.")
 
 
 @pytest.mark.parametrize("split", [False, True])
