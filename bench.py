@@ -229,8 +229,9 @@ def main():
     pipelined = not args.no_pipeline and not args.eager
     if args.streams > 1 and not pipelined:
         raise SystemExit("--streams needs the pipelined runner")
-    # the third stream pays off when ONE stream's chain of dependent launches bounds the frame (347 vs 335 frames/s); with
-    # several streams or a batch the chip is busy anyway and the extra launches cost (8 streams: 308 vs 394 per GPU)
+    # taking the single-frame decoder layer off the temporal chain pays off when ONE stream's chain of dependent launches
+    # bounds the frame (348 vs 335 frames/s); with several streams or a batch the chip is busy anyway and the extra
+    # launches cost (8 streams: 368 vs 394 per GPU)
     split = pipelined and not args.no_split and args.streams == 1 and args.bs == 1
     runners = []
     for _ in range(args.streams):  # one model replica + runner per independent stream
@@ -299,7 +300,7 @@ def main():
         head0 = runner.head
         n2 = [int(x) for x in head0.layers[0].last.count.sum(dim=1).tolist()] if head0.layers[0].last else None
         mode = dict(runner.stats, hipgraph=not args.eager, capacity_2d=args.capacity,
-                    pipelined_backbone=pipelined, single_frame_layer_on_third_stream=split)
+                    pipelined_backbone=pipelined, single_frame_layer_beside_previous_frame=split)
         def pmc_traffic(kernel):
             """HBM-side bytes per launch of `kernel` from the newest committed PMC passes (profiles/r*_sampler_traffic.json;
             rocprofv3 --pmc cannot run inside this process: tools/profile_round.py takes them with this same command),

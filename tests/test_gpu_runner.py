@@ -225,7 +225,7 @@ def test_pipelined_runner_overflow_with_a_decoder_already_enqueued_behind(split)
 
 
 def test_split_runner_equals_two_stream_runner_bit_for_bit():
-    """40 frames of synthetic features through PipelinedRunner and SplitPipelinedRunner (graphs, three streams, part A of
+    """40 frames of synthetic features through PipelinedRunner and SplitPipelinedRunner (graphs, part A of
     frame t beside part B of frame t-1): the same launches on the same numbers, so every detection, score and track id must
     be IDENTICAL, frame by frame -- a stale staging buffer, a flag row touched by the wrong frame or a part B that started
     before its part A would show here."""
@@ -342,7 +342,7 @@ def test_pipelined_equals_plain_runner_with_real_backbone():
     def snapshot(fm):
         return [t.clone() for t in list(fm)[:3]]
 
-    for name in ("graph", "pipe", "pipe_h2d", "pipe_split"):   # pipe_split: + the single-frame decoder layer on a third stream
+    for name in ("graph", "pipe", "pipe_h2d", "pipe_split"):   # pipe_split: + the single-frame decoder layer beside the previous frame's temporal part
         model = make()
         seen = []
         if name.startswith("pipe"):

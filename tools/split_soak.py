@@ -1,5 +1,5 @@
-"""Soak of runner.SplitPipelinedRunner: N frames of synthetic features (the golden stream's generator) through the two-stream
-and the three-stream runner, every detection compared bit for bit; then the three-stream runner again beside a second,
+"""Soak of runner.SplitPipelinedRunner: N frames of synthetic features (the golden stream's generator) through the plain
+and the split runner, every detection compared bit for bit; then the split runner again beside a second,
 unrelated runner that keeps the chip busy. usage: python tools/split_soak.py [frames]"""
 import os
 import sys
@@ -50,7 +50,7 @@ def run(split, busy=False):
         if other is not None:
             other[1].collect()
     res.append(runner.flush())
-    print(("three streams" if split else "two streams") + (" beside a second runner" if busy else ""), runner.stats, flush=True)
+    print(("split runner" if split else "plain runner") + (" beside a second runner" if busy else ""), runner.stats, flush=True)
     return res[1:]
 
 
@@ -68,5 +68,5 @@ def same(a, b):
 
 
 ref = run(False)
-print("three streams vs two streams:", same(ref, run(True)), "frames differ of", frames)
-print("three streams beside a second runner vs two streams:", same(ref, run(True, busy=True)), "frames differ of", frames)
+print("split runner vs plain runner:", same(ref, run(True)), "frames differ of", frames)
+print("split runner beside a second runner vs plain runner:", same(ref, run(True, busy=True)), "frames differ of", frames)
