@@ -374,6 +374,15 @@ class PipelinedRunner(FrameRunner):
         return out
 
 
+def refinement_time_step(dt, max_time_interval, default_time_interval):
+    """The time step the refinement heads divide velocities by (instance_bank.py:87,108-113; csrc/bank.hip bank_get_kernel):
+    the gap to the previous frame where it is usable (non-zero and within max_time_interval), the default otherwise. f32
+    in, f32 out, compared in f32 like the kernel does."""
+    dt = np.asarray(dt, np.float32)
+    ok = (dt != 0) & (np.abs(dt) <= np.float32(max_time_interval))
+    return np.where(ok, dt, np.float32(default_time_interval)).astype(np.float32)
+
+
 class SplitPipelinedRunner(PipelinedRunner):
     """PipelinedRunner with the single-frame decoder layer taken off the temporal chain.
 
@@ -431,9 +440,8 @@ class SplitPipelinedRunner(PipelinedRunner):
                 pin["dt"][i] = float(m["timestamp"] - prev["img_metas"][i]["timestamp"])
             # the time step the refinement heads divide by (instance_bank.py:108-113, csrc/bank.hip bank_get_kernel): the
             # frame gap where it is usable, the default otherwise -- a function of the time stamps alone, in f32 like there
-            dt32 = pin["dt"].numpy()
-            ok = (dt32 != 0) & (np.abs(dt32) <= np.float32(bank.max_time_interval))
-            pin["ti"].copy_(torch.from_numpy(np.where(ok, dt32, np.float32(bank.default_time_interval)).astype(np.float32)))
+            pin["ti"].copy_(torch.from_numpy(refinement_time_step(pin["dt"].numpy(), bank.max_time_interval,
+                                                                  bank.default_time_interval)))
         with torch.cuda.stream(stream):
             self.proj2[slot].copy_(pin["proj"], non_blocking=True)
             self.ti_buf2[slot].copy_(pin["ti"], non_blocking=True)
