@@ -110,6 +110,7 @@ __global__ __launch_bounds__(512) void decode3d_kernel(float* __restrict__ rec3d
 #pragma unroll
     for (int k = 0; k < SIMPB_RECORD3D_WIDTH; ++k) o[k] = v[k];
     rank_of_anchor[(size_t)b * A + a] = r;
+    simpb::stores_retired();  // a second trip (K > 512) starts with nothing of this one in flight
   }
 }
 

@@ -23,4 +23,11 @@ __device__ __forceinline__ void loads_retired() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// Every vector-memory operation of this wave (stores included: gfx9 counts them in vmcnt) has completed. At the end of a
+// loop body that stores: the next trip's loads then never wait on a counted vmcnt with this trip's store in flight.
+__device__ __forceinline__ void stores_retired() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 }  // namespace simpb
