@@ -73,7 +73,7 @@ class KernelMeter:
         from simpb_amd.plugin import blocks, group_attn
         self.lib = _lib.lib()
         self.blocks, self.group_attn = blocks, group_attn
-        self.daf_orig, self.msda_orig = blocks.DAF, group_attn.ms_deform_attn_grouped
+        self.daf_orig, self.msda_orig, self.fused_orig = blocks.DAF, group_attn.ms_deform_attn_grouped, blocks.dfa_fused
         self.daf_calls, self.msda_calls = [], []
         self.enabled = False
         self.capacity = 8 * steps + 64
@@ -92,12 +92,25 @@ class KernelMeter:
                 self.msda_calls.append((tuple(loc.shape), value.shape[-1], qcam))
             return out
 
+        def fused(feat, ss, ssi, anchor, learn, fix_scale, proj, wh, feat_logits, cam_logits, groups, **kw):
+            out = self.fused_orig(feat, ss, ssi, anchor, learn, fix_scale, proj, wh, feat_logits, cam_logits, groups, **kw)
+            if self.enabled:   # the locations the launch computed on chip, recomputed outside the timed interval to count V
+                from simpb_amd.plugin import ops
+                loc = ops.dfa_locations(anchor, learn, fix_scale, proj, wh)
+                lvls = ss.shape[1]
+                self.daf_calls.append((loc, (loc.shape[0], loc.shape[1], loc.shape[2], loc.shape[3], lvls, groups), tuple(out.shape),
+                                       dict(feat_bytes=feat.element_size(), fused=True, logits=feat_logits.numel() + cam_logits.numel(),
+                                            small=anchor.numel() + learn.numel())))
+            return out
+
         self.blocks.DAF = daf
+        self.blocks.dfa_fused = fused
         self.group_attn.ms_deform_attn_grouped = msda
         return self
 
     def __exit__(self, *exc):
         self.blocks.DAF, self.group_attn.ms_deform_attn_grouped = self.daf_orig, self.msda_orig
+        self.blocks.dfa_fused = self.fused_orig
         self.lib.simpb_timing_enable(0)
 
     def start(self):
@@ -116,16 +129,28 @@ class KernelMeter:
         d = self._durations(self.DAF)
         if d and len(d) == len(self.daf_calls):
             nbytes = valid = 0.0
-            for loc, wshape, oshape in self.daf_calls:
+            kernel, s_f = "daf_fwd_rows", 4
+            for call in self.daf_calls:
+                loc, wshape, oshape = call[:3]
                 v = int(((loc > 0) & (loc < 1)).all(-1).sum())
-                w_elems = 1
-                for k in wshape:
-                    w_elems *= k
-                # V * L levels * 4 taps * C * 4 B + loc + weights + out
-                nbytes += v * wshape[4] * 4 * oshape[-1] * 4 + loc.numel() * 4 + w_elems * 4 + oshape[0] * oshape[1] * oshape[2] * 4
+                out_bytes = oshape[0] * oshape[1] * oshape[2] * 4
+                if len(call) > 3:
+                    # one-launch form (csrc/deform_agg_fused.hip): SURVEY.md §8(d) with s_f = the token element size it reads;
+                    # sampling locations and weights never exist in memory -- what it reads instead are the logits they are
+                    # made from (feat_logits + cam_logits) and the anchor / learnable-offset rows
+                    info = call[3]
+                    kernel, s_f = "daf_fused_rows", info["feat_bytes"]
+                    nbytes += v * wshape[4] * 4 * oshape[-1] * s_f + (info["logits"] + info["small"]) * 4 + out_bytes
+                else:
+                    w_elems = 1
+                    for k in wshape:
+                        w_elems *= k
+                    # V * L levels * 4 taps * C * 4 B + loc + weights + out
+                    nbytes += v * wshape[4] * 4 * oshape[-1] * 4 + loc.numel() * 4 + w_elems * 4 + out_bytes
                 valid += v
             n = len(d)
-            out["daf"] = dict(kernel="daf_fwd_rows", secs=sum(d) / n, nbytes=nbytes / n, launches=n, valid_triples=valid / n)
+            out["daf"] = dict(kernel=kernel, secs=sum(d) / n, nbytes=nbytes / n, launches=n, valid_triples=valid / n,
+                              feature_bytes_per_element=s_f)
         d = self._durations(self.MSDA)
         if d and len(d) == len(self.msda_calls):
             nbytes = 0.0
@@ -313,10 +338,11 @@ def main():
                     continue
             return None, None
 
-        feat_mb = 6 * sum((args.image_wh[1] // s) * (args.image_wh[0] // s) for s in (4, 8, 16, 32)) * 256 * 4 / 1e6
-        in_cache = feat_mb * 1e6 < 256 * 2 ** 20
+        tokens = 6 * sum((args.image_wh[1] // s) * (args.image_wh[0] // s) for s in (4, 8, 16, 32))
 
         def roofline(k, what):
+            feat_mb = tokens * 256 * k.get("feature_bytes_per_element", 4) / 1e6
+            in_cache = feat_mb * 1e6 < 256 * 2 ** 20
             ach = k["nbytes"] / k["secs"] / 1e9
             traffic, src = pmc_traffic(k["kernel"])
             r = dict(kernel=k["kernel"], bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
@@ -327,15 +353,15 @@ def main():
                      hbm_side_frac=(traffic / k["secs"] / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                      traffic_source=src,
                      note=f"{what}; achieved = algorithmic bytes (SURVEY.md 8d) / launch time measured by HIP events on the "
-                          f"launch stream in {k['launches']} instrumented launches right after the timed region; the fp32 feature "
-                          f"set is {feat_mb:.1f} MB and " + ("fits the 256 MiB Infinity Cache, so `achieved` is an on-die rate and can "
+                          f"launch stream in {k['launches']} instrumented launches right after the timed region; the feature "
+                          f"set it reads is {feat_mb:.1f} MB and " + ("fits the 256 MiB Infinity Cache, so `achieved` is an on-die rate and can "
                           "exceed the HBM peak: hbm_side_* = PMC bytes beyond L2 (2*FETCH_SIZE + WRITE_SIZE) / the same time"
                           if in_cache else "does not fit the 256 MiB Infinity Cache"))
             if "valid_triples" in k:
                 r["valid_triples"] = k["valid_triples"]
             return r
 
-        roof = roofline(ksum["daf"], "3D deformable aggregation (daf_fwd_rows)") if "daf" in ksum else None
+        roof = roofline(ksum["daf"], f"3D deformable aggregation ({ksum['daf']['kernel']}, {ksum['daf'].get('feature_bytes_per_element', 4)} B per token element)") if "daf" in ksum else None
         roof2 = roofline(ksum["msda"], "camera-grouped MSDeformAttn sampling over the value_proj output") if "msda" in ksum else None
         line = {
             "metric": "frames/sec (6-cam sample) + MSDeformAttn HBM GB/s, R50 704x256 @1/2/4/8 GPU",

@@ -54,6 +54,26 @@ int simpb_deformable_aggregation_forward(
     int batch_size, int num_cams, int num_feat, int num_embeds, int num_scale,
     int num_anchors, int num_pts, int num_groups, void* stream);
 
+/* DeformableFeatureAggregation.forward between its Linear layers in ONE launch (models/blocks.py:110-162): key points
+ * (models/detection3d/blocks.py:181-222) -> project_points (blocks.py:198-213) -> softmax of _get_weights (:177-187) ->
+ * the aggregation above. The workgroup that aggregates an anchor computes its num_pts x num_cams sampling locations and
+ * its softmax weights on chip, so neither tensor exists in memory (simpb_dfa_points + simpb_dfa_weights +
+ * simpb_deformable_aggregation_forward are the same arithmetic in three launches; tests compare the two).
+ *   mc_ms_feat   f32 (feat_is_f16 = 0) or f16 (1) [batch_size, num_feat, num_embeds]; the f16 form is for tokens that are
+ *                f16 numbers anyway (the fp16 backbone's output, simpb.py:63): same results, half the gather bytes
+ *   anchor f32 [bs, A, 11]; learnable f32 [bs, A, num_learn * 3] (raw learnable_fc output); fix_scale f32 [num_fix, 3]
+ *   projection_mat f32 [bs, cams, 4, 4]; image_wh f32 [bs, cams, 2]
+ *   feat_logits f32 [bs, A, num_scale * num_pts * num_groups] = weights_fc(feature + anchor_embed)
+ *   cam_logits  f32 [bs, cams, num_scale * num_pts * num_groups] = camera_embed . weights_fc.weight^T
+ *   loc_out / weights_out: optional (NULL) copies of the two on-chip tensors in the layouts of the operator above
+ * Supported layout: num_embeds <= 256, (num_embeds / num_groups) % 4 == 0, num_groups a power of two <= 64,
+ * num_pts * num_cams <= 128, cams * num_scale * num_pts * num_groups <= 4096; anything else returns SIMPB_EINVAL. */
+int simpb_dfa_fused_forward(
+    float* output, const void* mc_ms_feat, int feat_is_f16, const int* spatial_shape, const int* scale_start_index,
+    const float* anchor, const float* learnable, const float* fix_scale, const float* projection_mat, const float* image_wh,
+    const float* feat_logits, const float* cam_logits, float* loc_out, float* weights_out, int batch_size, int num_cams,
+    int num_feat, int num_embeds, int num_scale, int num_anchors, int num_fix, int num_learn, int num_groups, void* stream);
+
 /* Replaces `deformable_aggregation_grad(...)` (ops/src/deformable_aggregation.cpp:64-84, launcher
  * ops/src/deformable_aggregation_cuda.cu:291-318, kernels :62-126,190-262), the backward of the
  * operator (ops/deformable_aggregation.py:39-75). Layouts as the forward; grad_output f32
@@ -454,6 +474,16 @@ int simpb_gather_rows(float* out, const float* src, const int* q2a, int batch_si
 int simpb_aggregate_2d_to_3d(float* out_q, float* out_pos, const float* q3d, const float* pos3d, const float* q2d,
                              const float* pos2d, const float* alpha, const int* a2q, int batch_size,
                              int num_anchors, int num_cams, int num_query, int channels, void* stream);
+
+/* The same with ReWeight.alpha (models/aggregation.py:23-24) computed inside the launch instead of read from memory:
+ * alpha[b,s] = sigmoid(hidden[b,s,:] . w_alpha + b_alpha) with hidden f32 [bs, num_query, hidden_dim] (row stride
+ * ld_hidden) = ReLU(ReWeight.reduce(...)); every slot belongs to one anchor, so each alpha is computed once. hidden NULL:
+ * alpha is read as above. num_cams <= 8; hidden_dim % 4 == 0; hidden, w_alpha 16-byte aligned. */
+int simpb_aggregate_2d_to_3d_alpha(float* out_q, float* out_pos, const float* q3d, const float* pos3d, const float* q2d,
+                                   const float* pos2d, const float* alpha, const int* a2q, const float* hidden,
+                                   int ld_hidden, int hidden_dim, const float* w_alpha, const float* b_alpha,
+                                   int batch_size, int num_anchors, int num_cams, int num_query, int channels,
+                                   void* stream);
 
 #ifdef __cplusplus
 }

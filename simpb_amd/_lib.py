@@ -18,6 +18,7 @@ SIGNATURES = {
     "simpb_timing_read": ([_I, _P, _I], _I),
     "simpb_timing_reset": ([], None),
     "simpb_deformable_aggregation_forward": ([_P] * 6 + [_I] * 8 + [_P], _I),
+    "simpb_dfa_fused_forward": ([_P, _P, _I] + [_P] * 11 + [_I] * 9 + [_P], _I),
     "simpb_deformable_aggregation_backward": ([_P] * 9 + [_I] * 8 + [_P], _I),
     "simpb_ms_deform_attn_grouped_forward": ([_P] * 7 + [_I] * 8 + [_P], _I),
     "simpb_ms_deform_attn_grouped_backward": ([_P] * 10 + [_I] * 8 + [_P], _I),
@@ -51,6 +52,7 @@ SIGNATURES = {
     "simpb_alloc_static": ([_P] * 15 + [_I] * 4 + [_F] * 5 + [_P], _I),
     "simpb_gather_rows": ([_P] * 3 + [_I] * 4 + [_P], _I),
     "simpb_aggregate_2d_to_3d": ([_P] * 8 + [_I] * 5 + [_P], _I),
+    "simpb_aggregate_2d_to_3d_alpha": ([_P] * 9 + [_I, _I, _P, _P] + [_I] * 5 + [_P], _I),
 }
 
 ERRORS = {1: "SIMPB_EINVAL (bad pointer/size/layout)", 2: "SIMPB_ELAUNCH (kernel launch failed)"}

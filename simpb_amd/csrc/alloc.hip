@@ -200,26 +200,58 @@ __global__ void gather_rows_kernel(float* __restrict__ out, const float* __restr
 
 // ---- 2D -> 3D weighted mean (aggregation.py:30-35): for anchor a, over its <= cams slots s,
 //   out_q = q3d + sum alpha[s]*q2d[s] / clamp(sum alpha[s], 1e-5)   (same for the pos stream)
-__global__ void aggregate_kernel(float* __restrict__ out_q, float* __restrict__ out_pos,
-                                 const float* __restrict__ q3d, const float* __restrict__ pos3d,
-                                 const float* __restrict__ q2d, const float* __restrict__ pos2d,
-                                 const float* __restrict__ alpha, const int* __restrict__ a2q, int A, int cams, int N2,
-                                 int C4) {
+// alpha: given per slot, or (hidden != NULL) computed here as ReWeight.alpha (aggregation.py:23-24):
+// sigmoid(hidden[s] . w_alpha + b_alpha), one wave-wide dot per slot -- every slot belongs to exactly one anchor, so
+// nothing is computed twice and the separate row-dot launch goes away. One wave per anchor.
+constexpr int kMaxAggCams = 8;
+__global__ __launch_bounds__(64) void aggregate_kernel(float* __restrict__ out_q, float* __restrict__ out_pos,
+                                                       const float* __restrict__ q3d, const float* __restrict__ pos3d,
+                                                       const float* __restrict__ q2d, const float* __restrict__ pos2d,
+                                                       const float* __restrict__ alpha, const int* __restrict__ a2q, int A,
+                                                       int cams, int N2, int C4, const float* __restrict__ hidden, int ldh,
+                                                       int kh, const float* __restrict__ w_alpha,
+                                                       const float* __restrict__ b_alpha) {
   const int a = blockIdx.x, b = blockIdx.y;
   const int* slots = a2q + ((size_t)b * A + a) * cams;
+  float wgt[kMaxAggCams];
+  int slot[kMaxAggCams];
   float div = 0.f;
-  for (int k = 0; k < cams; ++k) {
-    const int s = slots[k];
-    if (s >= 0) div += alpha[(size_t)b * N2 + s];
+#pragma unroll
+  for (int k = 0; k < kMaxAggCams; ++k) {
+    slot[k] = k < cams ? slots[k] : -1;
+    wgt[k] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxAggCams; ++k) {
+    const int s = slot[k];   // wave-uniform
+    if (s < 0) continue;
+    float w;
+    if (hidden) {
+      const float* h = hidden + ((size_t)b * N2 + s) * ldh;
+      float d = 0.f;
+      for (int c = threadIdx.x * 4; c < kh; c += 256) {
+        const float4 xv = *reinterpret_cast<const float4*>(h + c);
+        const float4 wv = *reinterpret_cast<const float4*>(w_alpha + c);
+        d += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;   // rowdot_sigmoid_kernel's arithmetic (csrc/rowops.hip)
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m);
+      w = 1.f / (1.f + expf(-(d + (b_alpha ? b_alpha[0] : 0.f))));
+    } else {
+      w = alpha[(size_t)b * N2 + s];
+    }
+    wgt[k] = w;
+    div += w;
   }
   div = fmaxf(div, 1e-5f);
   const size_t row = ((size_t)b * A + a) * C4;
   for (int c = threadIdx.x; c < C4; c += blockDim.x) {
     float4 sq = make_float4(0.f, 0.f, 0.f, 0.f), sp = sq;
-    for (int k = 0; k < cams; ++k) {
-      const int s = slots[k];
+#pragma unroll
+    for (int k = 0; k < kMaxAggCams; ++k) {
+      const int s = slot[k];
       if (s < 0) continue;
-      const float w = alpha[(size_t)b * N2 + s];
+      const float w = wgt[k];
       const float4 vq = reinterpret_cast<const float4*>(q2d)[((size_t)b * N2 + s) * C4 + c];
       const float4 vp = reinterpret_cast<const float4*>(pos2d)[((size_t)b * N2 + s) * C4 + c];
       sq.x += w * vq.x; sq.y += w * vq.y; sq.z += w * vq.z; sq.w += w * vq.w;
@@ -308,18 +340,35 @@ extern "C" int simpb_gather_rows(float* out, const float* src, const int* q2a, i
   return status();
 }
 
+extern "C" int simpb_aggregate_2d_to_3d_alpha(float* out_q, float* out_pos, const float* q3d, const float* pos3d,
+                                              const float* q2d, const float* pos2d, const float* alpha, const int* a2q,
+                                              const float* hidden, int ld_hidden, int hidden_dim, const float* w_alpha,
+                                              const float* b_alpha, int batch_size, int num_anchors, int num_cams,
+                                              int num_query, int channels, void* stream) {
+  if (!out_q || !out_pos || !q3d || !pos3d || !q2d || !pos2d || !a2q || batch_size <= 0 || num_anchors <= 0 ||
+      num_cams <= 0 || num_cams > kMaxAggCams || num_query <= 0 || channels <= 0 || channels % 4 != 0 || batch_size > 65535)
+    return SIMPB_EINVAL;
+  if (hidden) {
+    if (!w_alpha || hidden_dim <= 0 || hidden_dim % 4 || ld_hidden < hidden_dim || (ld_hidden & 3) ||
+        (reinterpret_cast<size_t>(hidden) & 15) || (reinterpret_cast<size_t>(w_alpha) & 15))
+      return SIMPB_EINVAL;
+  } else if (!alpha) {
+    return SIMPB_EINVAL;
+  }
+  clear_stale();
+  hipLaunchKernelGGL(aggregate_kernel, dim3(num_anchors, batch_size), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     out_q, out_pos, q3d, pos3d, q2d, pos2d, alpha, a2q, num_anchors, num_cams, num_query, channels / 4,
+                     hidden, ld_hidden, hidden_dim, w_alpha, b_alpha);
+  return status();
+}
+
 extern "C" int simpb_aggregate_2d_to_3d(float* out_q, float* out_pos, const float* q3d, const float* pos3d,
                                         const float* q2d, const float* pos2d, const float* alpha, const int* a2q,
                                         int batch_size, int num_anchors, int num_cams, int num_query, int channels,
                                         void* stream) {
-  if (!out_q || !out_pos || !q3d || !pos3d || !q2d || !pos2d || !alpha || !a2q || batch_size <= 0 ||
-      num_anchors <= 0 || num_cams <= 0 || num_query <= 0 || channels <= 0 || channels % 4 != 0 || batch_size > 65535)
-    return SIMPB_EINVAL;
-  clear_stale();
-  hipLaunchKernelGGL(aggregate_kernel, dim3(num_anchors, batch_size), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     out_q, out_pos, q3d, pos3d, q2d, pos2d, alpha, a2q, num_anchors, num_cams, num_query,
-                     channels / 4);
-  return status();
+  if (!alpha) return SIMPB_EINVAL;
+  return simpb_aggregate_2d_to_3d_alpha(out_q, out_pos, q3d, pos3d, q2d, pos2d, alpha, a2q, nullptr, 0, 0, nullptr, nullptr,
+                                        batch_size, num_anchors, num_cams, num_query, channels, stream);
 }
 
 extern "C" int simpb_alloc_static(unsigned char* flag, float* sel_xy, float* depth, int* count, int* order, int* group_start,

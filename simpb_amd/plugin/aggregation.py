@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from . import dense
+from . import dense, routes
 from .allocation import Allocation2D, aggregate_2d_to_3d
 from .registry import ATTENTION, PLUGIN_LAYERS, build_from_cfg
 
@@ -42,7 +42,7 @@ class AdaptiveQueryAggregation(nn.Module):
             raise NotImplementedError("denoising queries only exist in training")
         if allocation is None:
             allocation = _from_dense(trans_matrix, center_matrix)
-        if dense.ENABLED and query2d.is_cuda and query2d.shape[-1] % 64 == 0 and allocation.is_center.dtype == torch.int32:
+        if routes.R.dense and query2d.is_cuda and query2d.shape[-1] % 64 == 0 and allocation.is_center.dtype == torch.int32:
             # ReWeight (:10-40) in two launches: reduce over cat(query2d, is_center) as one GEMM whose
             # 257th input column is a flagged extra bias, then the alpha row-dot + sigmoid
             m_live = kwargs.get("m_live")
@@ -50,6 +50,11 @@ class AdaptiveQueryAggregation(nn.Module):
             w_x, w_flag = dense.fold_split_last_column(red)
             hidden = dense.linear(query2d, w_x, red.bias, relu=True, m_live=m_live,
                                   row_flag=allocation.is_center.contiguous().reshape(-1), bias2=w_flag)
+            if allocation.a2q.shape[-1] <= 8:   # alpha = sigmoid(alp(hidden)) inside the aggregation launch
+                query3d, query_pos3d = aggregate_2d_to_3d(query3d, query_pos3d, query2d, query_pos2d, None, allocation.a2q,
+                                                          hidden=hidden, alpha_fc=alp)
+                aggregated = graph_model(self.self_attn, query=query3d, query_pos=query_pos3d, attn_mask=attn_mask)
+                return aggregated, query_pos3d, anchor3d
             alpha = dense.rowdot_sigmoid(hidden, alp.weight, alp.bias, m_live=m_live)
         else:
             center_param = torch.cat([query2d, allocation.is_center[..., None].to(query2d.dtype)], dim=-1)

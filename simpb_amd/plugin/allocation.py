@@ -11,9 +11,9 @@ from .ops import _ptr, _require_gpu, _stream
 from .registry import PLUGIN_LAYERS
 
 
-# True: with a fixed capacity the allocation steps run as three launches (simpb_alloc_static); False: five, one per step
-# (the route the exact-size mode always takes), also the cross-check in tests.
-FUSED_STATIC = True
+# routes.alloc_static_fused: with a fixed capacity the allocation steps run as three launches (simpb_alloc_static); off:
+# five, one per step (the route the exact-size mode always takes), also the cross-check in tests.
+from . import routes
 
 
 class Allocation2D:
@@ -81,7 +81,7 @@ class DynamicQueryAllocation(nn.Module):
         st = _stream()
         count = torch.empty(bs, cams, dtype=torch.int32, device=dev)
         order = torch.empty(bs, cams, num_anchor, dtype=torch.int32, device=dev)
-        static = capacity is not None and FUSED_STATIC and cams <= 8
+        static = capacity is not None and routes.R.alloc_static_fused and cams <= 8
         if not static:
             _lib.check(lib.simpb_alloc_project(_ptr(flag), _ptr(sel_xy), _ptr(depth), _ptr(anchor3d), _ptr(proj), bs,
                                                num_anchor, cams, img_w, img_h, lw, ll, lh, st), "simpb_alloc_project")
@@ -152,10 +152,14 @@ def gather_rows(src, q2a):
     return out
 
 
-def aggregate_2d_to_3d(q3d, pos3d, q2d, pos2d, alpha, a2q):
-    """aggregation.py:30-35,88-89 as one kernel over the (anchor, cam) -> slot table."""
-    _require_gpu(q3d, pos3d, q2d, pos2d, alpha, a2q)
+def aggregate_2d_to_3d(q3d, pos3d, q2d, pos2d, alpha, a2q, hidden=None, alpha_fc=None):
+    """aggregation.py:30-35,88-89 as one kernel over the (anchor, cam) -> slot table. alpha: per-slot weights [bs, N2, 1],
+    or None with `hidden` [bs, N2, k] and `alpha_fc` (the Linear(k, 1) of ReWeight.alpha): the kernel then computes
+    sigmoid(alpha_fc(hidden)) itself (aggregation.py:23-24)."""
+    _require_gpu(q3d, pos3d, q2d, pos2d, a2q)
     q3d, pos3d, q2d, pos2d = (t.contiguous().float() for t in (q3d, pos3d, q2d, pos2d))
+    if alpha is None:
+        return _aggregate_alpha(q3d, pos3d, q2d, pos2d, a2q, hidden, alpha_fc)
     alpha = alpha.contiguous().float()
     bs, num_anchor, c = q3d.shape
     n2 = q2d.shape[1]
@@ -170,4 +174,22 @@ def aggregate_2d_to_3d(q3d, pos3d, q2d, pos2d, alpha, a2q):
     _lib.check(_lib.lib().simpb_aggregate_2d_to_3d(_ptr(out_q), _ptr(out_pos), _ptr(q3d), _ptr(pos3d), _ptr(q2d),
                                                    _ptr(pos2d), _ptr(alpha), _ptr(a2q), bs, num_anchor, cams, n2, c,
                                                    _stream()), "simpb_aggregate_2d_to_3d")
+    return out_q, out_pos
+
+
+def _aggregate_alpha(q3d, pos3d, q2d, pos2d, a2q, hidden, alpha_fc):
+    bs, num_anchor, c = q3d.shape
+    n2, cams = q2d.shape[1], a2q.shape[-1]
+    hidden = hidden.contiguous().float()
+    k = hidden.shape[-1]
+    w = alpha_fc.weight.reshape(-1).float().contiguous()
+    if (tuple(pos3d.shape) != (bs, num_anchor, c) or tuple(q2d.shape) != (bs, n2, c) or tuple(pos2d.shape) != (bs, n2, c)
+            or tuple(hidden.shape) != (bs, n2, k) or w.numel() != k or tuple(a2q.shape) != (bs, num_anchor, cams)
+            or a2q.dtype != torch.int32 or not a2q.is_contiguous() or c % 4 or k % 4 or n2 == 0):
+        raise ValueError("aggregate_2d_to_3d: inconsistent shapes")
+    out_q, out_pos = torch.empty_like(q3d), torch.empty_like(pos3d)
+    _lib.check(_lib.lib().simpb_aggregate_2d_to_3d_alpha(
+        _ptr(out_q), _ptr(out_pos), _ptr(q3d), _ptr(pos3d), _ptr(q2d), _ptr(pos2d), None, _ptr(a2q), _ptr(hidden), k, k, _ptr(w),
+        _ptr(alpha_fc.bias) if alpha_fc.bias is not None else None, bs, num_anchor, cams, n2, c, _stream()),
+        "simpb_aggregate_2d_to_3d_alpha")
     return out_q, out_pos

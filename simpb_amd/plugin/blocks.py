@@ -3,10 +3,11 @@ DenseDepthNet, which is an auxiliary training loss only: simpb.py:83-86,104-107)
 import torch
 import torch.nn as nn
 
-from . import dense
+from . import dense, routes
 from .layers import (BaseModule, Linear, Sequential, build_activation_layer, build_dropout, build_norm_layer,
                      linear_relu_ln)
 from .ops import deformable_aggregation_function as DAF
+from .ops import dfa_fused
 from .registry import ATTENTION, FEEDFORWARD_NETWORK, PLUGIN_LAYERS, build_from_cfg
 
 __all__ = ["DeformableFeatureAggregation", "DenseDepthNet", "AsymmetricFFN"]
@@ -100,7 +101,7 @@ class DeformableFeatureAggregation(BaseModule):
         if cam_embed is None:  # the head hands in the embeddings of all its layers, computed in one launch
             cam_embed = fused.chain_forward(self.camera_encoder, proj[:, :, :3].reshape(bs, self.num_cams, -1))
         # weights_fc(f + e) = [f | e] . [W | W]^T + b; weights_fc(f + e + c) = that + c . W^T (no second bias)
-        if dense.ENABLED:
+        if routes.R.dense:
             learn, feat_logits, cam_logits = dense.gemm(
                 dense.job(instance_feature, kps.learnable_fc.weight, kps.learnable_fc.bias),
                 dense.job([instance_feature, anchor_embed], dense.fold_sum_input(self.weights_fc), self.weights_fc.bias),
@@ -110,6 +111,18 @@ class DeformableFeatureAggregation(BaseModule):
             learn = kps.learnable_fc(instance_feature).contiguous()
             feat_logits = linear_f32(instance_feature + anchor_embed, self.weights_fc.weight, self.weights_fc.bias)
             cam_logits = linear_f32(cam_embed, self.weights_fc.weight)
+        shipped_layout = (self.num_cams == 6 and self.num_levels == 4 and self.num_groups == 8 and self.embed_dims == 256
+                          and kps.fix_scale.shape[0] == 7 and kps.num_learnable_pts == 6)   # what the one-launch kernel is compiled for
+        if routes.R.fused_dfa and routes.R.dense and shipped_layout:
+            # key points + projection + weight softmax inside the aggregation launch (csrc/deform_agg_fused.hip), reading the
+            # f16 copy of the tokens where the FPN left one (the tokens are f16 numbers: same bits, half the gather bytes)
+            feat = feature_maps[0]
+            half = getattr(feat, "simpb_f16", None) if routes.R.dfa_f16_tokens else None
+            if half is not None and half.shape == feat.shape:
+                feat = half
+            features = dfa_fused(feat, feature_maps[1], feature_maps[2], anchor_c, learn, kps.fix_scale, proj, wh, feat_logits,
+                                 cam_logits, self.num_groups)
+            return self._project_out(features, instance_feature, keep_parts)
         num_fix = kps.fix_scale.shape[0]
         loc = torch.empty(bs, num_anchor, self.num_pts, self.num_cams, 2, device=dev)
         _lib.check(lib.simpb_dfa_points(_ptr(loc), None, _ptr(anchor_c), _ptr(learn), _ptr(kps.fix_scale), _ptr(proj),
@@ -120,7 +133,10 @@ class DeformableFeatureAggregation(BaseModule):
                                          self.num_cams, self.num_levels, self.num_pts, self.num_groups, _stream()),
                    "simpb_dfa_weights")
         features = DAF(*feature_maps, loc, weights).reshape(bs, num_anchor, self.embed_dims)
-        if dense.ENABLED:
+        return self._project_out(features, instance_feature, keep_parts)
+
+    def _project_out(self, features, instance_feature, keep_parts):
+        if routes.R.dense:
             output = dense.linear(features, self.output_proj.weight, self.output_proj.bias)
         else:
             output = self.output_proj(features)
@@ -231,11 +247,11 @@ class AsymmetricFFN(BaseModule):
 
     def forward(self, x, identity=None, m_live=None):
         first = x[0] if isinstance(x, dense.Segments) else x
-        if dense.ENABLED and first.is_cuda and identity is None and not self.training and self._fusable():
+        if routes.R.dense and first.is_cuda and identity is None and not self.training and self._fusable():
             # blocks.py:384-393 in three launches: pre-norm over the (possibly two-segment) input,
             # fc1 + ReLU, then [h | x] . [W_2 | W_id]^T + b_2 + b_id (dense.fold_ffn_out)
-            xn = dense.layernorm(x, self.pre_norm, m_live=m_live)
             fc1, fc2 = self.layers[0][0], self.layers[1]
+            xn = dense.layernorm(x, self.pre_norm, m_live=m_live)
             h = dense.linear(xn, fc1.weight, fc1.bias, relu=True, m_live=m_live)
             w, b = dense.fold_ffn_out(fc2, self.identity_fc)
             return dense.linear([h, xn], w, b, m_live=m_live)

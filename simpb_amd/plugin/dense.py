@@ -18,22 +18,19 @@ from .ops import _stream
 
 MAX_SEGS, MAX_JOBS = 4, 4
 
-# True: the decoder's query-sized Linear layers go through csrc/gemm.hip (grouped, segment-input
-# GEMMs with host-folded weights). False: one GEMM per nn.Linear plus the cat/add kernels around it,
-# where every module boundary of the reference exists -- kept for A/B measurements and as the route
-# on which tests/test_gpu_head.py compares every golden trace record.
-ENABLED = True
-
-# True: weights are also handed over split into two half-precision parts, and launches whose segments are
-# 128-aligned run on the FP16 matrix cores in four split passes at fp32-grade accuracy (csrc/gemm.hip:
-# gemm_f16x3_kernel; 25-35 % faster per launch, tests/test_dense.py bounds its error like the exact kernel's).
-# False (default): always the exact fp32 matrix-core kernel. Off by default because the gain at frame level is
-# small (296 -> 301 frames/s: the launches are latency-, not matrix-bound) and because a different -- equally
-# accurate -- rounding moved one 2D query of the golden R50 stream across the image border (N2 1129 vs 1130 in one
-# layer of one frame): the allocation's inside/outside tests sit downstream of every product, ~1e-6 of the 583k
-# point tests of a stream fall within rounding distance of a border, and the golden vectors were matched
-# slot for slot with the exact kernels.
-SPLIT_FP16 = False
+# routes.dense: the decoder's query-sized Linear layers go through csrc/gemm.hip (grouped, segment-input GEMMs with
+# host-folded weights). Off: one GEMM per nn.Linear plus the cat/add kernels around it, where every module boundary of
+# the reference exists -- kept for A/B measurements and as the route on which tests/test_gpu_head.py compares every
+# golden trace record.
+# routes.gemm_split_fp16: weights are also handed over split into two half-precision parts, and launches whose segments
+# are 128-aligned run on the FP16 matrix cores in four split passes at fp32-grade accuracy (csrc/gemm.hip:
+# gemm_f16x3_kernel; 25-35 % faster per launch, tests/test_dense.py bounds its error like the exact kernel's). Off
+# (shipped): always the exact fp32 matrix-core kernel, because the gain at frame level is small (296 -> 301 frames/s: the
+# launches are latency-, not matrix-bound) and because a different -- equally accurate -- rounding moved one 2D query of
+# the golden R50 stream across the image border (N2 1129 vs 1130 in one layer of one frame): the allocation's
+# inside/outside tests sit downstream of every product, ~1e-6 of the 583k point tests of a stream fall within rounding
+# distance of a border, and the golden vectors were matched slot for slot with the exact kernels.
+from . import routes
 
 
 def _split_weights(w):
@@ -172,7 +169,7 @@ def gemm(*jobs):
             bias = bias.float().contiguous()
         jb.num_seg, jb.M, jb.N, jb.K = len(spec["xs"]), m, n, k
         jb.w, jb.ldw = w.data_ptr(), w.stride(0)
-        if SPLIT_FP16 and w.is_contiguous() and all(x.shape[-1] % 128 == 0 for x in spec["xs"]):
+        if routes.R.gemm_split_fp16 and w.is_contiguous() and all(x.shape[-1] % 128 == 0 for x in spec["xs"]):
             w_hi, w_lo = _split_weights(w)
             jb.w_hi, jb.w_lo = w_hi.data_ptr(), w_lo.data_ptr()
             keep += [w_hi, w_lo]

@@ -13,9 +13,9 @@ assert (X, Y, Z, W, L, H, SIN_YAW, COS_YAW) == tuple(range(8))
 from .layers import BaseModule, Linear, Scale, bias_init_with_prob, linear_relu_ln
 from .registry import BBOX_CODERS, PLUGIN_LAYERS, POSITIONAL_ENCODING
 
-# True: decode_static_device builds its two records with csrc/decode.hip (two launches); False: the
+# routes.fused_decode: decode_static_device builds its two records with csrc/decode.hip (two launches); off: the
 # PyTorch statement of the same arithmetic (~40 launches), kept as the cross-check in tests/test_gpu_runner.py.
-FUSED_DECODE = True
+from . import routes
 
 __all__ = ["SparseBox3DRefinementModule", "SparseBox3DKeyPointsGenerator", "SparseBox3DEncoder", "SparseBox3DDecoder"]
 
@@ -360,7 +360,7 @@ class SparseBox3DDecoder(object):
         rec2d = 4 decoded box + score + label + rank of the slot's anchor in the sorted top-k (or -1)
         + camera of the slot (or -1)."""
         cls3, box3 = cls_scores[output_idx], box_preds[output_idx]
-        if (FUSED_DECODE and cls3.is_cuda and self.score_threshold is None and self.sorted and cls3.shape[1] <= 1024
+        if (routes.R.fused_decode and cls3.is_cuda and self.score_threshold is None and self.sorted and cls3.shape[1] <= 1024
                 and self.num_output <= 512 and box3.shape[-1] == 11 and alloc.q2a.dtype == torch.int32):
             return self._decode_static_fused(cls3, box3, instance_id, qulity[output_idx] if qulity is not None else None,
                                              cls_scores2d[output_idx2d], box_preds2d[output_idx2d], alloc, aug_config)

@@ -17,15 +17,14 @@ from .registry import BACKBONES, DETECTORS, HEADS, NECKS, PLUGIN_LAYERS, build_f
 __all__ = ["SimPB", "ResNet", "FPN"]
 
 
-# True: conv1 / conv3 / downsample of the fp16 bottlenecks run as csrc/conv1x1.hip (one launch each, epilogue
-# included); False: vendor convolution + csrc/bias_act.hip (two launches), also the cross-check in tests.
-CONV1X1_KERNEL = True
-# True: conv2 of the fp16 bottlenecks and the FPN's output convolutions run as csrc/conv3x3.hip (implicit GEMM, epilogue
-# included; the FPN's write the decoder's fp32 tokens themselves); False: vendor convolution (+ csrc/bias_act.hip / the
-# token format pass), also the cross-check in tests.
-CONV3X3_KERNEL = True
-# True: the stem's bias + ReLU + 3x3/2 max-pool as one pass (csrc/bias_act.hip); False: csrc/bias_act.hip + PyTorch's pooling
-STEM_EPILOGUE_KERNEL = True
+# routes.conv1x1_kernel: conv1 / conv3 / downsample of the fp16 bottlenecks run as csrc/conv1x1.hip (one launch each,
+# epilogue included); off: vendor convolution + csrc/bias_act.hip (two launches), also the cross-check in tests.
+# routes.conv3x3_kernel: conv2 of the fp16 bottlenecks and the FPN's output convolutions run as csrc/conv3x3.hip (implicit
+# GEMM, epilogue included; the FPN's write the decoder's tokens themselves); off: vendor convolution (+ csrc/bias_act.hip
+# / the token format pass), also the cross-check in tests.
+# routes.stem_epilogue_kernel: the stem's bias + ReLU + 3x3/2 max-pool as one pass (csrc/bias_act.hip); off: bias_act +
+# PyTorch's pooling.
+from . import routes
 
 
 class Bottleneck(nn.Module):
@@ -61,7 +60,7 @@ class Bottleneck(nn.Module):
             return F.conv2d(t, m.weight, None, m.stride, m.padding)
 
         def takes(m, t):
-            return (CONV1X1_KERNEL and m.in_channels % 64 == 0 and m.out_channels % 8 == 0 and m.stride[0] in (1, 2)
+            return (routes.R.conv1x1_kernel and m.in_channels % 64 == 0 and m.out_channels % 8 == 0 and m.stride[0] in (1, 2)
                     and m.stride[0] == m.stride[1] and t.is_contiguous(memory_format=torch.channels_last))
 
         def pointwise(m, t, residual=None, relu=True, input_bias=None):
@@ -75,7 +74,7 @@ class Bottleneck(nn.Module):
         identity = x if self.downsample is None else pointwise(self.downsample[0], x, None, relu=False)
         out = pointwise(self.conv1, x)
         c2 = self.conv2
-        if (CONV3X3_KERNEL and c2.in_channels % 64 == 0 and c2.out_channels % 8 == 0 and c2.stride[0] in (1, 2)
+        if (routes.R.conv3x3_kernel and c2.in_channels % 64 == 0 and c2.out_channels % 8 == 0 and c2.stride[0] in (1, 2)
                 and c2.stride[0] == c2.stride[1] and c2.padding == (1, 1) and out.is_contiguous(memory_format=torch.channels_last)):
             # the 3x3 convolution as one implicit-GEMM launch with its bias + ReLU (csrc/conv3x3.hip)
             out = conv3x3_nhwc(out, c2.weight, c2.bias, relu=True, stride=c2.stride[0])
@@ -127,7 +126,7 @@ class ResNet(BaseModule):
             from .ops import bias_act_, bias_relu_maxpool
             x = F.conv2d(x, self.conv1.weight, None, self.conv1.stride, self.conv1.padding)
             mp = self.maxpool
-            if (STEM_EPILOGUE_KERNEL and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1 and mp.dilation == 1
+            if (routes.R.stem_epilogue_kernel and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1 and mp.dilation == 1
                     and not mp.ceil_mode and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)):
                 x = bias_relu_maxpool(x, self.conv1.bias)   # bias + ReLU + max-pool in one pass (bit-equal to the two)
             else:
@@ -176,7 +175,7 @@ class FPN(BaseModule):
 
     def forward(self, inputs):
         x0 = inputs[self.start_level]
-        if (CONV1X1_KERNEL and x0.is_cuda and x0.dtype == torch.float16 and self.upsample_cfg.get("mode") == "nearest"
+        if (routes.R.conv1x1_kernel and x0.is_cuda and x0.dtype == torch.float16 and self.upsample_cfg.get("mode") == "nearest"
                 and all(t.is_contiguous(memory_format=torch.channels_last) for t in inputs)
                 and all(m.conv.in_channels % 64 == 0 and m.conv.out_channels % 8 == 0 for m in self.lateral_convs)):
             # lateral 1x1 convolutions as csrc/conv1x1.hip launches, the top-down sum riding along as the residual:
@@ -198,7 +197,7 @@ class FPN(BaseModule):
                 laterals[i] = conv1x1_nhwc(xin, conv.weight, conv.bias, up, relu=False, residual_upsample2x=up2x)
             tokens_for = getattr(self, "tokens_for", None)   # (bs, num_cams) set by SimPB.extract_feat for this call
             self.wrote_tokens = None
-            if (CONV3X3_KERNEL and tokens_for is not None
+            if (routes.R.conv3x3_kernel and tokens_for is not None
                     and all(m.conv.in_channels % 64 == 0 and m.conv.out_channels % 8 == 0 and m.conv.padding == (1, 1)
                             and m.conv.stride == (1, 1) and m.conv.bias is not None for m in self.fpn_convs)):
                 # the output convolutions write the decoder's fp32 token buffer themselves (csrc/conv3x3.hip): no f16 maps,

@@ -8,15 +8,15 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from . import routes
 from .layers import Scale
 from .ops import _stream
 
 MAX_OPS, MAX_CHAINS = 12, 8
 POST_NONE, POST_REFINE3D, POST_REFINE2D, POST_SIGMOID = 0, 1, 2, 3
-TRANSPOSED_WEIGHTS = False  # False: matrix-core kernel on the weights as stored; True: VALU kernel on transposed copies
-# True (shipped): 4-row workgroups on the 4x4 matrix blocks, weights k4-packed [in/4][out][4] (csrc/mlp_chain.hip:
-# mlp_chain_r4_kernel): 225 workgroups for 900 rows instead of 57. Takes precedence over TRANSPOSED_WEIGHTS.
-ROWS4 = True
+# routes.chain_rows4 (shipped): 4-row workgroups on the 4x4 matrix blocks, weights k4-packed [in/4][out][4]
+# (csrc/mlp_chain.hip: mlp_chain_r4_kernel): 225 workgroups for 900 rows instead of 57. Off: the 16-row matrix-core kernel
+# on the weights as stored, or (routes.chain_transposed) the VALU kernel on transposed copies.
 LINEAR, LAYERNORM = 0, 1
 IN_ROWS, IN_SINE2D = 0, 1
 
@@ -99,11 +99,11 @@ class ChainPlan:
             op = chain.ops[j]
             op.type, op.in_dim, op.out_dim, op.relu = typ, din, dout, relu
             if typ == LINEAR:
-                if ROWS4 and din % 4 == 0:
+                if routes.R.chain_rows4 and din % 4 == 0:
                     wp = self._packed(m)
                     keep.append(wp)
                     op.w = wp.data_ptr()
-                elif TRANSPOSED_WEIGHTS and not ROWS4:
+                elif routes.R.chain_transposed and not routes.R.chain_rows4:
                     wt = self._transposed(m)
                     keep.append(wt)
                     op.w = wt.data_ptr()
@@ -150,7 +150,7 @@ def run_chains(jobs, num_rows, device, m_live=None):
     args = _Args()
     args.num_rows, args.num_chains = int(num_rows), len(jobs)
     args.m_live = m_live.data_ptr() if m_live is not None else None
-    args.weights_transposed = 2 if ROWS4 else (1 if TRANSPOSED_WEIGHTS else 0)
+    args.weights_transposed = 2 if routes.R.chain_rows4 else (1 if routes.R.chain_transposed else 0)
     keep = []
     for c, job in enumerate(jobs):
         ch = args.chain[c]

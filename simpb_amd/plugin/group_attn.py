@@ -9,7 +9,7 @@ from . import dense
 from .layers import BaseModule, build_dropout, mha_forward
 from .ops import linear_f32, linear_split, ms_deform_attn_grouped, query_cam_from_groups
 
-SPLIT_VALUE_PROJ = True  # False: the exact-fp32 matrix-core kernel (csrc/linear.hip), 3.5x slower on this shape
+from . import routes
 from .registry import ATTENTION
 
 
@@ -104,9 +104,9 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
         """value_proj over every camera token (:176-179): the largest GEMM of the decoder."""
         # fp32-grade product on the FP16 matrix cores (three split passes); the camera tokens are the output of
         # the fp16 backbone, well inside the half-precision range the split needs
-        lin = linear_split if SPLIT_VALUE_PROJ else linear_f32
+        lin = linear_split if routes.R.split_value_proj else linear_f32
         half = getattr(value, "simpb_f16", None)   # the FPN left the same tokens in f16 (detector.FPN): two passes suffice
-        if SPLIT_VALUE_PROJ and half is not None and half.shape == value.shape:
+        if routes.R.split_value_proj and half is not None and half.shape == value.shape:
             value = half
         value = lin(value, self.value_proj.weight, self.value_proj.bias)
         if key_padding_mask is not None:
@@ -120,7 +120,7 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
             value = query
         if identity is None:
             identity = query
-        fused = (dense.ENABLED and query.is_cuda and query_pos is not None and self.batch_first
+        fused = (routes.R.dense and query.is_cuda and query_pos is not None and self.batch_first
                  and query.shape == query_pos.shape)
         raw_query = query
         if query_pos is not None and not fused:

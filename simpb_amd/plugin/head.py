@@ -11,7 +11,7 @@ from . import training_stubs  # noqa: F401  (registers the inert training-only c
 from .allocation import gather_rows
 from .registry import (ATTENTION, BBOX_CODERS, BBOX_SAMPLERS, FEEDFORWARD_NETWORK, HEADS, LOSSES, NORM_LAYERS,
                        PLUGIN_LAYERS, POSITIONAL_ENCODING, TRANSFORMER_LAYER_SEQUENCE, build_from_cfg)
-from . import dense
+from . import dense, routes
 from .layers import BaseModule, fused_graph_attention
 
 __all__ = ["SimPBHead"]
@@ -163,7 +163,7 @@ class SimPBHead(BaseModule):
         """simpb_head.py:298-310."""
         layer = self.layers[index] if isinstance(index, int) else index
         kwargs.pop("attn_mask", None)
-        if query.is_cuda and dense.ENABLED:
+        if query.is_cuda and routes.R.dense:
             out = fused_graph_attention(layer, self.fc_before, self.fc_after, query, query_pos, key, key_pos, value)
             if out is not None:
                 return out
@@ -176,7 +176,7 @@ class SimPBHead(BaseModule):
 
     def graph_model2d(self, index, query, key=None, value=None, query_pos=None, key_pos=None, **kwargs):
         """simpb_head.py:312-321."""
-        if self.decouple_attn2d and query.is_cuda and dense.ENABLED and kwargs.get("query_cam") is not None:
+        if self.decouple_attn2d and query.is_cuda and routes.R.dense and kwargs.get("query_cam") is not None:
             out = fused_graph_attention(self.layers[index], self.fc_before2d, self.fc_after2d, query, query_pos, key,
                                         key_pos, value, query_cam=kwargs["query_cam"],
                                         group_start=kwargs.get("group_start"), m_live=self._m_live)
@@ -197,7 +197,7 @@ class SimPBHead(BaseModule):
         proj = metas.get("projection_mat")
         idx = [i for i, op in enumerate(self.operation_order)
                if op == "deformable" and getattr(self.layers[i], "camera_encoder", None) is not None]
-        if proj is None or not proj.is_cuda or not idx or len(idx) > 8 or not dense.ENABLED:
+        if proj is None or not proj.is_cuda or not idx or len(idx) > 8 or not routes.R.dense:
             return {}
         from . import fused
         cam_in = proj[:, :, :3].reshape(batch_size * self.num_cams, -1).float().contiguous()
@@ -310,7 +310,7 @@ class SimPBHead(BaseModule):
             if layer is None:
                 continue
             elif op == "norm":
-                if instance_feature.is_cuda and dense.ENABLED:
+                if instance_feature.is_cuda and routes.R.dense:
                     instance_feature = dense.layernorm(instance_feature, layer, m_live=self._m_live)
                 else:
                     instance_feature = layer(instance_feature)
@@ -349,7 +349,7 @@ class SimPBHead(BaseModule):
                 instance_feature = layer(query=instance_feature, query_pos=anchor_embed2d,
                                          reference_points=anchor2d.unsqueeze(2), query_groups=ref_query_groups,
                                          query_cam=alloc.query_cam, m_live=self._m_live,
-                                         keep_parts=dense.ENABLED and self._next_is_ffn(i), **enc)
+                                         keep_parts=routes.R.dense and self._next_is_ffn(i), **enc)
             elif op == "refine2d":
                 kw = dict(m_live=self._m_live) if self._m_live is not None else {}
                 anchor2d, cls2d, depth2d, alpha2d = layer(instance_feature, anchor2d, anchor_embed2d, metas=metas,
@@ -370,7 +370,7 @@ class SimPBHead(BaseModule):
                 temp_attn_instance = instance_feature
             elif op == "deformable":
                 instance_feature = layer(instance_feature, anchor, anchor_embed, feature_maps, metas,
-                                         keep_parts=dense.ENABLED and self._next_is_ffn(i),
+                                         keep_parts=routes.R.dense and self._next_is_ffn(i),
                                          cam_embed=cam_embeds.get(i))
             elif op == "refine3d":
                 anchor, cls, qt = layer(

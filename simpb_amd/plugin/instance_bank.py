@@ -14,10 +14,10 @@ from .registry import PLUGIN_LAYERS, build_from_cfg
 
 __all__ = ["InstanceBank"]
 
-# True: with the persistent (static) state the three touch points of a frame run as csrc/bank.hip launches
-# (1 + 2 + 2) instead of ~70 PyTorch launches; False: the PyTorch statement below, which is also what the
+# routes.fused_bank: with the persistent (static) state the three touch points of a frame run as csrc/bank.hip
+# launches (1 + 2 + 2) instead of ~70 PyTorch launches; off: the PyTorch statement below, which is also what the
 # eager (non-static) mode always runs and what tests compare the kernels with.
-FUSED_BANK = True
+from . import routes
 
 _STATE_FIELDS = ("cached_feature", "cached_anchor", "confidence", "instance_id", "prev_id")
 
@@ -232,7 +232,7 @@ class InstanceBank(nn.Module):
         self.has_history = True
 
     def _fusable(self, t):
-        return (FUSED_BANK and self._static is not None and t.is_cuda and self.anchor.shape[-1] == 11
+        return (routes.R.fused_bank and self._static is not None and t.is_cuda and self.anchor.shape[-1] == 11
                 and self.num_anchor <= 1024 and 0 < self.num_temp_instances < self.num_anchor
                 and self.embed_dims % 4 == 0)
 

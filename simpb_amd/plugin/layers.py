@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import routes
 from .registry import ATTENTION, NORM_LAYERS
 
 Linear = nn.Linear
@@ -77,8 +78,7 @@ def linear_relu_ln(embed_dims, in_loops, out_loops, input_dims=None):
 
 # Measured on MI355X (round 1): forking the value branch of each attention operator onto a side stream
 # LOSES time inside the replayed frame graph (179-188 -> 163 frames/s): a cross-stream edge in a
-# hipGraph costs more than two ~12 us GEMMs gain by overlapping. Kept for experiments, off by default.
-PARALLEL_BRANCHES = False
+# hipGraph costs more than two ~12 us GEMMs gain by overlapping. Kept for experiments (routes.parallel_branches), off.
 _side_streams = {}
 
 
@@ -87,7 +87,7 @@ def run_parallel(fn_a, fn_b, device):
     (e.g. the q/k projection and the value path of an attention operator) each occupy well under
     half of the 256 CUs, so they are forked and joined instead of serialised. Works the same inside
     a graph capture (the fork/join becomes graph edges) and in eager mode."""
-    if not PARALLEL_BRANCHES or device.type != "cuda":
+    if not routes.R.parallel_branches or device.type != "cuda":
         return fn_a(), fn_b()
     cur = torch.cuda.current_stream(device)
     key = (device.index, cur.cuda_stream)

@@ -103,6 +103,59 @@ def deformable_aggregation_function(feature_maps, spatial_shape, scale_start_ind
     return DeformableAggregationFunction.apply(feature_maps, spatial_shape, scale_start_index, sampling_location, weights)
 
 
+def dfa_fused(feat, spatial_shape, scale_start_index, anchor, learn, fix_scale, proj, image_wh, feat_logits, cam_logits,
+              num_groups, want_operands=False):
+    """DeformableFeatureAggregation between its Linear layers as ONE launch (csrc/deform_agg_fused.hip): key points,
+    projection, weight softmax and the aggregation. feat: the token buffer, f32 or f16 [bs, num_feat, C]. Returns the
+    aggregated features [bs, A, C] (and, with want_operands, the sampling locations and weights the launch used, in the
+    drop-in operator's layouts)."""
+    _require_gpu(feat, anchor, learn, feat_logits, cam_logits, proj, image_wh)
+    if feat.dtype not in (torch.float32, torch.float16) or not feat.is_contiguous():
+        raise ValueError("dfa_fused: contiguous f32 or f16 token buffer expected")
+    bs, num_feat, c = feat.shape
+    cams, lvls = spatial_shape.shape[:2]
+    a = anchor.shape[1]
+    num_fix, num_learn = fix_scale.shape[0], learn.shape[-1] // 3
+    p = num_fix + num_learn
+    spatial_shape = spatial_shape.contiguous().int()
+    scale_start_index = scale_start_index.contiguous().int()
+    anchor, learn = anchor.contiguous().float(), learn.contiguous().float()
+    feat_logits, cam_logits = feat_logits.contiguous().float(), cam_logits.contiguous().float()
+    proj, image_wh = proj.contiguous().float(), image_wh.contiguous().float()
+    fix_scale = fix_scale.contiguous().float()
+    lpg = lvls * p * num_groups
+    if (tuple(anchor.shape) != (bs, a, 11) or tuple(learn.shape) != (bs, a, num_learn * 3) or tuple(feat_logits.shape) != (bs, a, lpg)
+            or tuple(cam_logits.shape) != (bs, cams, lpg) or tuple(proj.shape) != (bs, cams, 4, 4) or tuple(image_wh.shape) != (bs, cams, 2)
+            or tuple(spatial_shape.shape) != (cams, lvls, 2) or tuple(scale_start_index.shape) != (cams, lvls)):
+        raise ValueError("dfa_fused: operand shapes disagree")
+    _check_layout(spatial_shape, scale_start_index, num_feat)
+    out = torch.empty(bs, a, c, device=feat.device, dtype=torch.float32)
+    loc = torch.empty(bs, a, p, cams, 2, device=feat.device) if want_operands else None
+    w = torch.empty(bs, a, p, cams, lvls, num_groups, device=feat.device) if want_operands else None
+    status = _lib.lib().simpb_dfa_fused_forward(
+        _ptr(out), _ptr(feat), 1 if feat.dtype == torch.float16 else 0, _ptr(spatial_shape), _ptr(scale_start_index),
+        _ptr(anchor), _ptr(learn), _ptr(fix_scale), _ptr(proj), _ptr(image_wh), _ptr(feat_logits), _ptr(cam_logits),
+        _ptr(loc) if loc is not None else None, _ptr(w) if w is not None else None, bs, cams, num_feat, c, lvls, a, num_fix,
+        num_learn, num_groups, _stream())
+    _lib.check(status, "simpb_dfa_fused_forward")
+    return (out, loc, w) if want_operands else out
+
+
+def dfa_locations(anchor, learn, fix_scale, proj, image_wh):
+    """Sampling locations [bs, A, P, cams, 2] of DeformableFeatureAggregation's key points (csrc/dfa_prep.hip:
+    dfa_points): what the one-launch form computes on chip; used by measurement code to count valid samples."""
+    _require_gpu(anchor, learn, proj, image_wh)
+    anchor, learn = anchor.contiguous().float(), learn.contiguous().float()
+    proj, image_wh, fix_scale = proj.contiguous().float(), image_wh.contiguous().float(), fix_scale.contiguous().float()
+    bs, a = anchor.shape[:2]
+    cams = proj.shape[1]
+    num_fix, num_learn = fix_scale.shape[0], learn.shape[-1] // 3
+    loc = torch.empty(bs, a, num_fix + num_learn, cams, 2, device=anchor.device)
+    _lib.check(_lib.lib().simpb_dfa_points(_ptr(loc), None, _ptr(anchor), _ptr(learn), _ptr(fix_scale), _ptr(proj), _ptr(image_wh),
+                                           bs, a, num_fix, num_learn, cams, _stream()), "simpb_dfa_points")
+    return loc
+
+
 def feature_maps_format(feature_maps, inverse=False):
     """ops/__init__.py:22-92. Forward direction: list of [bs, cam, C, H, W] ->
     [col_feats [bs, sum(cam*H*W), C], spatial_shape i64[cam, lvl, 2], scale_start_index i64[cam, lvl]].

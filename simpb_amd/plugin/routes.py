@@ -1,0 +1,91 @@
+"""The product path's route table: which of two equivalent implementations a module takes where it has a choice.
+
+The SHIPPED value of every entry is its default below and nothing in the product changes it: the table is read-only
+outside `override()`, a context manager for tests and measurement tools that want the other branch of one switch (an A/B
+timing, the unfused route on which every module boundary of the reference exists and is compared with the golden
+traces, a vendor-library cross-check). One table instead of a dozen mutable module globals: a test cannot leave a
+switch flipped behind it (the manager restores on exit, also after an exception), and `routes.R` shows at a glance
+what a frame runs.
+
+    from simpb_amd.plugin import routes
+    with routes.override(dense=False):      # tests/test_gpu_head.py "unfused"
+        ...
+"""
+import contextlib
+
+DEFAULTS = dict(
+    # decoder dense layers as grouped segment-input GEMMs with host-folded weights (plugin/dense.py, csrc/gemm.hip).
+    # False: one GEMM per nn.Linear plus the cat/add kernels around it -- every module boundary of the reference exists.
+    dense=True,
+    # grouped GEMM on the FP16 matrix cores with split operands (fp32-grade, 25-35 % faster per launch, +2 % per frame):
+    # off, a differently rounded product moved one 2D query of the golden R50 stream across an image border (dense.py)
+    gemm_split_fp16=False,
+    # MLP chains: 4-row workgroups on the 4x4 matrix blocks with k4-packed weights (csrc/mlp_chain.hip). False +
+    # chain_transposed False: the 16-row matrix-core kernel on the weights as stored; chain_transposed: the VALU kernel.
+    chain_rows4=True,
+    chain_transposed=False,
+    # value_proj (group_attn.py:176) on the FP16 matrix cores with split operands. False: exact-fp32 kernel, 3.5x slower.
+    split_value_proj=True,
+    # decode_with2d's fixed-shape records by csrc/decode.hip (two launches). False: the PyTorch statement (~40 launches).
+    fused_decode=True,
+    # InstanceBank on its persistent state through csrc/bank.hip. False: the PyTorch statement of instance_bank.py.
+    fused_bank=True,
+    # fork the value branch of an attention operator onto a side stream (measured slower inside a replayed graph)
+    parallel_branches=False,
+    # own 1x1 / 3x3 convolutions and stem epilogue (csrc/conv1x1.hip, conv3x3.hip, bias_act.hip). False: vendor
+    # convolutions (mmdet's statement of ResNet / FPN), the cross-check of tests/test_dense.py.
+    conv1x1_kernel=True,
+    conv3x3_kernel=True,
+    stem_epilogue_kernel=True,
+    # own 7x7 / stride-2 stem convolution (csrc/stem.hip). False: the vendor convolution.
+    stem_kernel=True,
+    # static-capacity allocation as one three-kernel entry point. False: the stepwise entry points.
+    alloc_static_fused=True,
+    # DeformableFeatureAggregation: key points + projection + weight softmax inside the aggregation launch
+    # (csrc/deform_agg_fused.hip). False: dfa_points + dfa_weights + the drop-in aggregation operator (three launches).
+    fused_dfa=True,
+    # ... reading the f16 copy of the camera tokens the FPN leaves beside the fp32 rows (same bits, half the bytes)
+    dfa_f16_tokens=True,
+)
+
+
+class _Routes:
+    __slots__ = tuple(DEFAULTS) + ("_open",)
+
+    def __init__(self):
+        object.__setattr__(self, "_open", False)
+        for k, v in DEFAULTS.items():
+            object.__setattr__(self, k, v)
+
+    def __setattr__(self, name, value):
+        if not self._open:
+            raise AttributeError(f"routes.R.{name} is read-only: use `with routes.override({name}=...)` (tests / tools only)")
+        if name not in DEFAULTS:
+            raise AttributeError(f"no route named {name!r}")
+        object.__setattr__(self, name, bool(value))
+
+    def __repr__(self):
+        return "Routes(" + ", ".join(f"{k}={getattr(self, k)}" for k in DEFAULTS) + ")"
+
+
+R = _Routes()
+
+
+@contextlib.contextmanager
+def override(**switches):
+    """Take the other branch of the named switches inside the block (tests and measurement tools only)."""
+    unknown = [k for k in switches if k not in DEFAULTS]
+    if unknown:
+        raise KeyError(f"no such route(s): {unknown}")
+    old = {k: getattr(R, k) for k in switches}
+    object.__setattr__(R, "_open", True)
+    try:
+        for k, v in switches.items():
+            setattr(R, k, v)
+        object.__setattr__(R, "_open", False)
+        yield R
+    finally:
+        object.__setattr__(R, "_open", True)
+        for k, v in old.items():
+            setattr(R, k, v)
+        object.__setattr__(R, "_open", False)

@@ -111,9 +111,14 @@ def _ref(xs, w, b, relu):
     (65, 70, [64, 64, 64, 64], False, True),     # four segments
 ])
 @pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_fp16"])
-def test_gemm_vs_float64(m, n, ks, relu, bias, split, monkeypatch):
+def test_gemm_vs_float64(m, n, ks, relu, bias, split):
     """split_fp16: the FP16-matrix-core variant (used when every segment is 128-aligned) must meet the same bound."""
-    monkeypatch.setattr(dense, "SPLIT_FP16", split)
+    from simpb_amd.plugin import routes
+    with routes.override(gemm_split_fp16=split):
+        _gemm_vs_float64(m, n, ks, relu, bias)
+
+
+def _gemm_vs_float64(m, n, ks, relu, bias):
     rs = torch.Generator().manual_seed(m * 7 + n)
     xs = [torch.randn(m, k, generator=rs) for k in ks]
     w = torch.randn(n, sum(ks), generator=rs) / np.sqrt(sum(ks))
@@ -353,13 +358,10 @@ def test_fused_decode_records_match_the_pytorch_statement():
     alloc = SimpleNamespace(q2a=q2a, query_cam=cam)
     aug = dict(crop=(0, 140, 704, 396), resize=0.44)
     dec = SparseBox3DDecoder(num_output=300)
-    try:
-        detection3d.FUSED_DECODE = False
+    from simpb_amd.plugin import routes
+    with routes.override(fused_decode=False):
         want3, want2 = dec.decode_static_device(cls, box, ids, quality, cls2d, box2d, alloc, aug)
-        detection3d.FUSED_DECODE = True
-        got3, got2 = dec.decode_static_device(cls, box, ids, quality, cls2d, box2d, alloc, aug)
-    finally:
-        detection3d.FUSED_DECODE = True
+    got3, got2 = dec.decode_static_device(cls, box, ids, quality, cls2d, box2d, alloc, aug)
     from simpb_amd.dist import lanes_to_ids
     assert got3.shape == want3.shape == (bs, 300, 15) and got2.shape == want2.shape == (bs, N2, 8)
     assert float((got3[..., :13] - want3[..., :13]).abs().max()) < 2e-4      # boxes/scores ~1e-6
@@ -378,7 +380,7 @@ def test_fused_decode_records_match_the_pytorch_statement():
 def test_fused_bank_matches_the_pytorch_bank_over_a_stream():
     """csrc/bank.hip (get / update / cache + ids on the persistent state) against the PyTorch statement of
     instance_bank.py:79-196 run on the same static state, 4 frames, 2 streams, one stream with a stale gap."""
-    from simpb_amd.plugin import instance_bank as ib
+    from simpb_amd.plugin import instance_bank as ib, routes
     from simpb_amd import synth
     g = torch.Generator().manual_seed(41)
     bs, A, T, C = 2, 900, 600, 256
@@ -403,7 +405,10 @@ def test_fused_bank_matches_the_pytorch_bank_over_a_stream():
                            cls2=torch.randn(bs, A, 10, generator=g).cuda()))
 
     def run(fused):
-        ib.FUSED_BANK = fused
+        with routes.override(fused_bank=fused):
+            return _run(fused)
+
+    def _run(fused):
         bank, out = make(), []
         with torch.no_grad():
             for f, fr in enumerate(frames):
@@ -421,10 +426,7 @@ def test_fused_bank_matches_the_pytorch_bank_over_a_stream():
                 out.append(rec)
         return out
 
-    try:
-        want, got = run(False), run(True)
-    finally:
-        ib.FUSED_BANK = True
+    want, got = run(False), run(True)
     for f, (w, gt) in enumerate(zip(want, got)):
         for k in w:
             if w[k] is None:
@@ -634,15 +636,12 @@ def test_fused_neck_equals_unfused_neck():
     with torch.no_grad():
         got = model.extract_feat(img)           # conv1x1 + conv3x3 kernels, the FPN writes the tokens itself
         assert not model.img_neck.deferred_output_bias
-        old = detector.CONV1X1_KERNEL, detector.CONV3X3_KERNEL
-        try:
-            detector.CONV3X3_KERNEL = False      # vendor 3x3 convolutions, biases added by the token format pass
+        from simpb_amd.plugin import routes
+        with routes.override(conv3x3_kernel=False, stem_kernel=False):   # vendor 3x3 convolutions, biases added by the token format pass
             mid = model.extract_feat(img)
             assert model.img_neck.deferred_output_bias
-            detector.CONV1X1_KERNEL = False      # mmdet's statement: lateral convs, F.interpolate, adds, biased 3x3 convs
-            want = model.extract_feat(img)
-        finally:
-            detector.CONV1X1_KERNEL, detector.CONV3X3_KERNEL = old
+            with routes.override(conv1x1_kernel=False):   # mmdet's statement: lateral convs, F.interpolate, adds, biased 3x3 convs
+                want = model.extract_feat(img)
         assert not model.img_neck.deferred_output_bias
     scale = float(want[0].abs().max())
     assert float((mid[0] - want[0]).abs().max()) <= 2e-2 * scale

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from simpb_amd import synth
+from simpb_amd.plugin import routes
 from tests.helpers import build_product_head, load_golden, metas_to, spec_of
 
 pytestmark = pytest.mark.gpu
@@ -75,12 +76,8 @@ def test_static_allocation_call_equals_the_stepwise_kernels(bs, capacity):
     anchor = anchor.cuda()
     outs = []
     for fused in (True, False):
-        old = allocation.FUSED_STATIC
-        try:
-            allocation.FUSED_STATIC = fused
+        with routes.override(alloc_static_fused=fused):
             a, pts, depth, _, _ = layer.allocate(anchor, metas, capacity=capacity)
-        finally:
-            allocation.FUSED_STATIC = old
         outs.append([a.q2a, a.is_center, a.a2q, a.query_cam, a.count, a.group_start, a.overflow, pts, depth])
     for x, y in zip(*outs):
         assert torch.equal(x, y)

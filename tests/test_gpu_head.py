@@ -19,14 +19,11 @@ FOLDED_AWAY = (r"^L\d+\.(gnn|temp_gnn|qg_self_attn)\.",)
 
 
 def run_product_stream(g, frames=None, fused=True):
-    from simpb_amd.plugin import dense, ops
+    from simpb_amd.plugin import ops, routes
     spec = spec_of(g)
     head = build_product_head(spec)
-    dense.ENABLED = fused
-    try:
+    with routes.override(dense=fused):
         yield from _run_stream(head, spec, frames, ops)
-    finally:
-        dense.ENABLED = True
 
 
 def _run_stream(head, spec, frames, ops):

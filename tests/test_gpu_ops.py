@@ -23,7 +23,7 @@ def _oracle():
 
 def test_library_loaded():
     from simpb_amd import _lib
-    assert _lib.lib().simpb_abi_version() == 4
+    assert _lib.lib().simpb_abi_version() == 5
 
 
 def test_daf_golden_fallback_case():
@@ -204,15 +204,67 @@ def test_dfa_producers_vs_oracle():
     from simpb_amd.plugin import blocks
     orig = blocks.DAF
     blocks.DAF = lambda f, ss, ssi, loc, w: got.update(loc=loc, w=w) or torch.zeros(bs, A, 256, device="cuda")
+    from simpb_amd.plugin import routes
     try:
         dfa.cuda()
         m = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in metas.items()}
-        with torch.no_grad():
+        with torch.no_grad(), routes.override(fused_dfa=False):   # the three-launch route, where both operands exist in memory
             dfa(feat.cuda(), anchor.cuda(), emb.cuda(), [None, None, None], m)
     finally:
         blocks.DAF = orig
     assert float((got["loc"].cpu() - want_loc).abs().max()) <= 1e-4 * max(1.0, float(want_loc.abs().max()) * 1e-2)
     assert float((got["w"].cpu() - want_w).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("f16", [False, True], ids=["f32_tokens", "f16_tokens"])
+def test_dfa_fused_launch_equals_three_launches(f16):
+    """The shipped one-launch form of DeformableFeatureAggregation (csrc/deform_agg_fused.hip: key points, projection,
+    weight softmax and aggregation in one kernel, optionally on the f16 copy of the tokens) against the three-launch form
+    through the drop-in operator: same sampling locations and weights (they come back through the optional outputs), same
+    module output; and the f16 token copy gives the same bits as the widened rows."""
+    from simpb_amd import configs, plugin
+    from simpb_amd.plugin import blocks, ops, routes
+    cfg = configs.simpb_plus(anchor=synth.anchors(900))["model"]["head"]["deformable_model"]
+    dfa = plugin.build_from_cfg(cfg, plugin.ATTENTION).eval().cuda()
+    synth.load_procedural(dfa, seed=2)
+    bs, A, wh = 2, 77, (352, 128)
+    fm = ops.feature_maps_format([x.cuda() for x in synth.feature_maps_nchw(bs, 0, wh)])
+    if f16:
+        fm[0] = fm[0].half().float()          # tokens that ARE f16 numbers, as the fp16 backbone leaves them
+        fm[0].simpb_f16 = fm[0].half()
+    fm = [fm[0], fm[1].int().contiguous(), fm[2].int().contiguous()]
+    feat = torch.from_numpy(synth.randn("dfa.feat", (bs, A, 256))).cuda()
+    emb = torch.from_numpy(synth.randn("dfa.emb", (bs, A, 256))).cuda()
+    anchor = torch.from_numpy(synth.anchors(A, seed=4))[None].repeat(bs, 1, 1).cuda()
+    anchor[..., :2] *= 0.5   # more key points inside the images
+    m = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth.frame_metas(bs, 0, wh).items()}
+    seen = {}
+    orig, orig_fused = blocks.DAF, blocks.dfa_fused
+    blocks.DAF = lambda f, ss, ssi, loc, w: seen.update(loc=loc, w=w) or orig(f, ss, ssi, loc, w)
+
+    def spy(*args, **kw):
+        out, loc, w = orig_fused(*args, want_operands=True, **kw)
+        seen.update(floc=loc, fw=w, fdtype=args[0].dtype)
+        return out
+    blocks.dfa_fused = spy
+    try:
+        with torch.no_grad():
+            with routes.override(fused_dfa=False):
+                want = dfa(feat, anchor, emb, fm, m)
+            got = dfa(feat, anchor, emb, fm, m)
+    finally:
+        blocks.DAF, blocks.dfa_fused = orig, orig_fused
+    assert seen["fdtype"] == (torch.float16 if f16 else torch.float32)
+    valid = ((seen["loc"] > 0) & (seen["loc"] < 1)).all(-1)
+    assert int(valid.sum()) > 200 and torch.equal(valid, ((seen["floc"] > 0) & (seen["floc"] < 1)).all(-1))
+    assert float((seen["floc"] - seen["loc"]).abs().max()) <= 1e-6 * max(1.0, float(seen["loc"].abs().max()))
+    assert float((seen["fw"] - seen["w"]).abs().max()) <= 1e-7
+    assert got.shape == want.shape == (bs, A, 512)
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    if f16:   # same launch on the widened rows: the same numbers (the compiler may contract the two loops differently)
+        with torch.no_grad(), routes.override(dfa_f16_tokens=False):
+            wide = dfa(feat, anchor, emb, fm, m)
+        assert float((wide - got).abs().max()) <= 2e-6 * max(1.0, float(got.abs().max()))
 
 
 @pytest.mark.parametrize("bs,nq,nk", [(1, 900, 600), (2, 77, 77), (1, 33, 1)])
@@ -345,16 +397,49 @@ def test_mlp_chain_kernel_variants_agree():
     enc = SparseBox3DEncoder(embed_dims=[128, 32, 32, 64], vel_dims=3, mode="cat", output_fc=False, in_loops=1, out_loops=4).cuda()
     synth.load_procedural(enc, seed=9)
     anchor = torch.randn(1, 333, 11, device="cuda")
-    old = fused.ROWS4, fused.TRANSPOSED_WEIGHTS
+    from simpb_amd.plugin import routes
     outs = {}
-    try:
-        for name, (r4, tr) in dict(rows4=(True, False), rows16=(False, False), valu=(False, True)).items():
-            fused.ROWS4, fused.TRANSPOSED_WEIGHTS = r4, tr
-            with torch.no_grad():
-                outs[name] = (fused.chain_forward(ref3.layers, x, e), enc(anchor))
-    finally:
-        fused.ROWS4, fused.TRANSPOSED_WEIGHTS = old
+    for name, (r4, tr) in dict(rows4=(True, False), rows16=(False, False), valu=(False, True)).items():
+        with routes.override(chain_rows4=r4, chain_transposed=tr), torch.no_grad():
+            outs[name] = (fused.chain_forward(ref3.layers, x, e), enc(anchor))
     for name in ("rows16", "valu"):
         for got, want in zip(outs["rows4"], outs[name]):
             assert got.shape == want.shape
             assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), name
+
+
+def test_aggregate_with_alpha_in_launch_equals_two_launches():
+    """ReWeight.alpha folded into the 2D -> 3D aggregation launch (csrc/alloc.hip) against the row-dot launch followed by the
+    aggregation on its output, and against the definition (aggregation.py:23-35) in float64."""
+    from simpb_amd.plugin import dense
+    from simpb_amd.plugin.allocation import aggregate_2d_to_3d
+    g = torch.Generator().manual_seed(3)
+    bs, A, cams, N2, C = 2, 50, 6, 130, 256
+    a2q = torch.full((bs, A, cams), -1, dtype=torch.int32)
+    for b in range(bs):   # every slot belongs to at most one (anchor, cam)
+        perm = torch.randperm(N2, generator=g)[:100]
+        pos = torch.randperm(A * cams, generator=g)[:100]
+        a2q[b].view(-1)[pos] = perm.to(torch.int32)
+    q3d, pos3d = torch.randn(bs, A, C, generator=g), torch.randn(bs, A, C, generator=g)
+    q2d, pos2d = torch.randn(bs, N2, C, generator=g), torch.randn(bs, N2, C, generator=g)
+    hidden = torch.relu(torch.randn(bs, N2, C, generator=g))
+    fc = torch.nn.Linear(C, 1)
+    with torch.no_grad():
+        fc.weight.copy_(torch.randn(1, C, generator=g) * 0.1)
+        fc.bias.fill_(0.3)
+    fc = fc.cuda()
+    args = [t.cuda() for t in (q3d, pos3d, q2d, pos2d)]
+    with torch.no_grad():
+        alpha = dense.rowdot_sigmoid(hidden.cuda(), fc.weight, fc.bias)
+        want = aggregate_2d_to_3d(*args, alpha, a2q.cuda())
+        got = aggregate_2d_to_3d(*args, None, a2q.cuda(), hidden=hidden.cuda(), alpha_fc=fc)
+    for x, y in zip(got, want):
+        assert float((x - y).abs().max()) <= 1e-6 * max(1.0, float(y.abs().max()))
+    al = torch.sigmoid(hidden.double() @ fc.weight.detach().cpu().double().t() + 0.3)[..., 0]
+    ref = q3d.double().clone()
+    for b in range(bs):
+        for a in range(A):
+            s = a2q[b, a][a2q[b, a] >= 0].long()
+            if len(s):
+                ref[b, a] += (al[b, s, None] * q2d[b, s].double()).sum(0) / al[b, s].sum().clamp(min=1e-5)
+    assert float((got[0].cpu().double() - ref).abs().max()) <= 2e-5

@@ -52,12 +52,11 @@ def main():
         ("encoder 2D sine (1536)", lambda: enc2(a2)),
         ("refine2d reg+cls+alpha (1536)", lambda: r2(f2, a2, e2)),
     ]:
-        from simpb_amd.plugin import fused
+        from simpb_amd.plugin import routes
         row = []
         for r4 in (True, False):
-            fused.ROWS4 = r4
-            row.append(timeit(fn))
-        fused.ROWS4 = True
+            with routes.override(chain_rows4=r4):
+                row.append(timeit(fn))
         print(f"{name:52s} rows4 {row[0]:7.1f} us   rows16 {row[1]:7.1f} us")
 
 

@@ -10,6 +10,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simpb_amd import configs, plugin, synth  # noqa: E402
 from simpb_amd.runner import PipelinedRunner  # noqa: E402
 
+# --route name=0/1 [...]: take the other branch of a route switch for this measurement (simpb_amd/plugin/routes.py)
+import contextlib  # noqa: E402
+from simpb_amd.plugin import routes  # noqa: E402
+_stack = contextlib.ExitStack()
+while "--route" in sys.argv:
+    i = sys.argv.index("--route")
+    k, v = sys.argv[i + 1].split("=")
+    _stack.enter_context(routes.override(**{k: bool(int(v))}))
+    del sys.argv[i:i + 2]
+print("routes:", routes.R, flush=True)
 wh = (704, 256)
 cfg = configs.simpb_plus(anchor=synth.anchors(900))
 model = plugin.build_detector(cfg["model"]).eval()
