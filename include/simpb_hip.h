@@ -105,6 +105,25 @@ int simpb_ms_deform_attn_grouped_forward(
     int batch_size, int num_cams, int num_value, int num_heads, int channels,
     int num_levels, int num_points, int num_query, void* stream);
 
+/* The same operator WITHOUT value_proj over the camera tokens (models/group_attn.py:176-179): sampling and the value
+ * projection are both linear, so for head h of a query
+ *   sum_s a_s bilinear(W_h x + b_h)(s) = W_h . [sum_s a_s bilinear(x)(s)] + b_h [sum_s a_s (valid tap weights of s)]
+ * (the reference zero-pads the PROJECTED map, hence the second bracket). This entry computes the brackets from the raw
+ * tokens; the caller applies W_h (folded with output_proj) as one query-sized product over agg. Softmax of the attention
+ * logits and reference point + offset / (W_l, H_l) (group_attn.py:181-201) are done here as well.
+ *   agg        f32 [batch_size, num_query, ld_agg >= 8 * 256 + 64]: per query [head][256 channel sums] | 8 tap-weight
+ *              sums | zeros up to 64; rows of capacity slots (query_cam < 0 or >= *m_live) are NOT written
+ *   tokens     f16 (tokens_are_f16 = 1) or f32 [batch_size, num_cams, num_value, 256]: the camera tokens themselves
+ *   raw        f32 [batch_size * num_query, ld_raw]: sampling_offsets (heads x levels x points x 2) | attention logits
+ *   ref        f32 [batch_size * num_query, ld_ref >= 2]: reference point (x, y) in [0, 1]
+ * Compiled for the shipped layout (8 heads x 32 channels, 4 levels, 4 points); anything else returns SIMPB_EINVAL and
+ * the caller uses value_proj + simpb_ms_deform_attn_grouped_forward. */
+int simpb_msda_linear_forward(float* agg, int ld_agg, const void* tokens, int tokens_are_f16,
+                              const long long* spatial_shapes, const long long* level_start, const float* raw,
+                              int ld_raw, const float* ref, int ld_ref, const int* query_cam, const int* m_live,
+                              int batch_size, int num_cams, int num_value, int num_heads, int channels,
+                              int num_levels, int num_points, int num_query, void* stream);
+
 /* Backward of simpb_ms_deform_attn_grouped_forward (what mmcv's ms_deform_attn_backward does per camera
  * group behind models/group_attn.py:227-235). grad_output f32 [bs, num_query, heads*channels]; all three
  * gradients are fully written (grad_value is cleared by the callee and accumulated with float atomics;

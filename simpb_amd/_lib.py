@@ -21,6 +21,7 @@ SIGNATURES = {
     "simpb_dfa_fused_forward": ([_P, _P, _I] + [_P] * 11 + [_I] * 9 + [_P], _I),
     "simpb_deformable_aggregation_backward": ([_P] * 9 + [_I] * 8 + [_P], _I),
     "simpb_ms_deform_attn_grouped_forward": ([_P] * 7 + [_I] * 8 + [_P], _I),
+    "simpb_msda_linear_forward": ([_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _P] + [_I] * 8 + [_P], _I),
     "simpb_ms_deform_attn_grouped_backward": ([_P] * 10 + [_I] * 8 + [_P], _I),
     "simpb_linear_f32": ([_P] * 4 + [_I] * 4 + [_P], _I),
     "simpb_linear_f16x3": ([_P] * 5 + [_I] * 3 + [_P], _I),

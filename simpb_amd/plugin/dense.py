@@ -312,6 +312,28 @@ def fold_ffn_out(fc2, identity_fc):
     return _folds.get(("ffn_out",), (fc2.weight, fc2.bias, identity_fc.weight, identity_fc.bias), build, owner=fc2)
 
 
+def fold_msda_linear(value_proj, output_proj, heads, width):
+    """QueryGroupMultiScaleDeformableAttention with value_proj moved behind the sampling (csrc/msda_lin.hip): the map from
+    agg = [per head: 256 sampled-token sums | per head: tap-weight sum | pad] to output_proj(concat_h(W_h agg_h + b_h s_h)):
+    weight [C, width], columns [h*256, (h+1)*256) = W_o[:, head h] . W_v[head h, :], column 8*256 + h = W_o[:, head h] . b_v[head h];
+    bias = b_o. float64 fold."""
+
+    def build():
+        wv, bv = _f64(value_proj.weight), _f64(value_proj.bias)
+        wo = _f64(output_proj.weight)
+        c = wv.shape[1]
+        hd = wv.shape[0] // heads
+        out = torch.zeros(wo.shape[0], width, dtype=torch.float64, device=wo.device)
+        for h in range(heads):
+            blk = wo[:, h * hd:(h + 1) * hd]
+            out[:, h * c:(h + 1) * c] = blk @ wv[h * hd:(h + 1) * hd]
+            out[:, heads * c + h] = blk @ bv[h * hd:(h + 1) * hd]
+        return out.float().contiguous(), output_proj.bias.detach().float().contiguous()
+
+    return _folds.get(("msda_linear", heads, width), (value_proj.weight, value_proj.bias, output_proj.weight, output_proj.bias),
+                      build, owner=value_proj)
+
+
 def fold_split_last_column(lin):
     """A Linear over cat(x, flag) with a 0/1 flag column: (weight over x [N, K-1] with 16-byte aligned
     rows, column of the flag [N])."""

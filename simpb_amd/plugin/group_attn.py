@@ -113,6 +113,27 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         return value
 
+    def _forward_linear(self, query, query_pos, identity, value, value_f16, reference_points, spatial_shapes,
+                        level_start_index, query_cam, m_live, keep_parts):
+        """The operator with value_proj moved behind the sampling (csrc/msda_lin.hip): three launches -- offsets | logits
+        product, sampling of the raw tokens (softmax and locations in its prologue), one product with the folded
+        W_out . W_value -- and no value tensor at all."""
+        from .ops import MSDA_LINEAR_WIDTH, msda_linear
+        bs, nq, _ = query.shape
+        w, b = dense.fold_stack("msda_in", [self.sampling_offsets, self.attention_weights], copies=2)
+        both = dense.linear([query, query_pos], w, b, m_live=m_live)
+        tokens = value_f16 if value_f16 is not None and value_f16.shape == value.shape else value
+        tokens = tokens.reshape(bs, self.num_cams, -1, self.embed_dims)
+        agg = msda_linear(tokens.contiguous(), spatial_shapes, level_start_index, both, reference_points, query_cam, m_live)
+        wf, bf = dense.fold_msda_linear(self.value_proj, self.output_proj, self.num_heads, MSDA_LINEAR_WIDTH)
+        output = dense.report(self.output_proj, dense.linear(agg, wf, bf, m_live=m_live))
+        if self.residual_mode == "add":
+            return output + identity
+        if self.residual_mode == "cat":
+            output = dense.Segments([output, identity])
+            return output if keep_parts else output.materialize()
+        return output
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, level_start_index=None, query_cam=None,
                 value_is_projected=False, m_live=None, keep_parts=False, **kwargs):
@@ -129,6 +150,14 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
             query = query.permute(1, 0, 2)
             value = value.permute(1, 0, 2)
         bs, num_query, _ = query.shape
+        linear_route = (routes.R.msda_linear and routes.R.dense and not value_is_projected and query.is_cuda and query_pos is not None
+                        and self.batch_first and query.shape == query_pos.shape and key_padding_mask is None
+                        and (self.num_heads, self.num_levels, self.num_points, self.embed_dims) == (8, 4, 4, 256)
+                        and reference_points.shape[-1] == 2 and value.dim() == 3 and value.shape[0] == bs * self.num_cams
+                        and value.shape[-1] == 256 and query_cam is not None)
+        if linear_route:
+            return self._forward_linear(raw_query, query_pos, identity, value, kwargs.get("value_f16"), reference_points,
+                                        spatial_shapes, level_start_index, query_cam, m_live, keep_parts)
         if value_is_projected:  # project_value() was already applied by the caller (head.precompute_values)
             num_value = value.shape[-2] if value.dim() == 3 and value.shape[0] == bs * self.num_cams else value.numel() // (bs * self.num_cams * self.embed_dims)
         else:

@@ -138,7 +138,9 @@ class SimPBHead(BaseModule):
                             spatial_shape[0].long().contiguous(), scale_start[0].long().contiguous())
         _, ss32, st32, ss_cam, st_cam = self._tables
         feat_flatten = col.reshape(bs, nc, -1, dim).flatten(0, 1)
+        half = getattr(col, "simpb_f16", None)   # the same tokens as the fp16 backbone left them (detector.FPN)
         encoder2d_dict = {
+            "value_f16": half.reshape(bs, nc, -1, dim).flatten(0, 1) if half is not None and half.shape == col.shape else None,
             "value": feat_flatten,
             "key_padding_mask": None,  # all-False in the reference (:286): masked_fill would be a no-op
             "spatial_shapes": ss_cam,
@@ -153,6 +155,8 @@ class SimPBHead(BaseModule):
         backbone, off the decoder's critical path. Returns {layer index: projected tokens}."""
         col = feature_maps[0]
         out = {}
+        if routes.R.msda_linear and routes.R.dense:
+            return out   # value_proj is applied behind the sampling (group_attn._forward_linear): nothing to precompute
         for i, op in enumerate(self.operation_order):
             if op == "qg_cross_attn":
                 out[i] = self.layers[i].project_value(col)

@@ -281,6 +281,40 @@ def ms_deform_attn_grouped(value, spatial_shapes, level_start_index, sampling_lo
                                              attention_weights, query_cam)
 
 
+MSDA_LINEAR_WIDTH = 8 * 256 + 64   # row of simpb_msda_linear_forward: 8 heads x 256 channel sums | 8 tap-weight sums | pad
+
+
+def msda_linear(tokens, spatial_shapes, level_start_index, raw, reference_points, query_cam, m_live=None):
+    """Camera-grouped deformable sampling of the RAW camera tokens (csrc/msda_lin.hip): what
+    QueryGroupMultiScaleDeformableAttention computes between its value_proj and its output_proj, with value_proj moved
+    behind the sampling by linearity. tokens f16 or f32 [bs, cams, Nv, 256]; raw [bs, Nq, 384] = sampling_offsets |
+    attention logits of [query | pos]; reference_points [bs, Nq, (1,) 2]; -> agg f32 [bs, Nq, 2112] (rows of capacity
+    slots are left unwritten: the product behind it skips them)."""
+    _require_gpu(tokens, raw, reference_points, query_cam)
+    if tokens.dtype not in (torch.float16, torch.float32) or not tokens.is_contiguous() or tokens.dim() != 4 or tokens.shape[-1] != 256:
+        raise ValueError("msda_linear: contiguous f16 / f32 tokens [bs, cams, Nv, 256] expected")
+    bs, cams, nv, _ = tokens.shape
+    nq = raw.shape[1]
+    spatial_shapes = spatial_shapes.contiguous().long()
+    level_start_index = level_start_index.contiguous().long()
+    if tuple(spatial_shapes.shape) != (4, 2) or tuple(level_start_index.shape) != (4,) or raw.shape[0] != bs or raw.shape[-1] != 384:
+        raise ValueError("msda_linear: the shipped layout (4 levels, 8 heads x 4 levels x 4 points) expected")
+    _check_layout(spatial_shapes[None], level_start_index[None], nv)
+    from .dense import rows2d
+    rawt, rows, ldraw = rows2d(raw)
+    reft, rrows, ldref = rows2d(reference_points.reshape(bs, nq, -1)[..., :2])
+    query_cam = query_cam.contiguous().int()
+    if rows != bs * nq or rrows != bs * nq or query_cam.numel() != nq:
+        raise ValueError("msda_linear: one raw row, one reference point and one camera per query slot")
+    agg = torch.empty(bs, nq, MSDA_LINEAR_WIDTH, device=tokens.device, dtype=torch.float32)
+    status = _lib.lib().simpb_msda_linear_forward(
+        _ptr(agg), MSDA_LINEAR_WIDTH, _ptr(tokens), 1 if tokens.dtype == torch.float16 else 0, _ptr(spatial_shapes),
+        _ptr(level_start_index), _ptr(rawt), ldraw, _ptr(reft), ldref, _ptr(query_cam),
+        _ptr(m_live) if m_live is not None else None, bs, cams, nv, 8, 32, 4, 4, nq, _stream())
+    _lib.check(status, "simpb_msda_linear_forward")
+    return agg
+
+
 def linear_f32(x, weight, bias=None, relu=False):
     """F.linear(x, weight, bias) (optionally + ReLU) in exact fp32 on the f32 matrix cores
     (csrc/linear.hip). x [..., K], weight [N, K]; K must be a multiple of 32."""

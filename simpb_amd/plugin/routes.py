@@ -41,6 +41,10 @@ DEFAULTS = dict(
     stem_kernel=True,
     # static-capacity allocation as one three-kernel entry point. False: the stepwise entry points.
     alloc_static_fused=True,
+    # QueryGroupMultiScaleDeformableAttention without value_proj over the 89 760 camera tokens: sample the raw tokens per
+    # (query, head), project the 8 x 256 sums with the folded W_out . W_value afterwards (csrc/msda_lin.hip; linearity).
+    # False: value_proj over every token (with the backbone, runner.precompute_values) + the sampler on its output.
+    msda_linear=True,
     # DeformableFeatureAggregation: key points + projection + weight softmax inside the aggregation launch
     # (csrc/deform_agg_fused.hip). False: dfa_points + dfa_weights + the drop-in aggregation operator (three launches).
     fused_dfa=True,
