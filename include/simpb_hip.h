@@ -111,8 +111,8 @@ int simpb_ms_deform_attn_grouped_forward(
  * (the reference zero-pads the PROJECTED map, hence the second bracket). This entry computes the brackets from the raw
  * tokens; the caller applies W_h (folded with output_proj) as one query-sized product over agg. Softmax of the attention
  * logits and reference point + offset / (W_l, H_l) (group_attn.py:181-201) are done here as well.
- *   agg        f32 [batch_size, num_query, ld_agg >= 8 * 256 + 64]: per query [head][256 channel sums] | 8 tap-weight
- *              sums | zeros up to 64; rows of capacity slots (query_cam < 0 or >= *m_live) are NOT written
+ *   agg        f32 [batch_size, num_query, ld_agg >= 8 * 256 + 128]: per query [head][256 channel sums] | 8 tap-weight
+ *              sums | zeros up to 128; rows of capacity slots (query_cam < 0 or >= *m_live) are NOT written
  *   tokens     f16 (tokens_are_f16 = 1) or f32 [batch_size, num_cams, num_value, 256]: the camera tokens themselves
  *   raw        f32 [batch_size * num_query, ld_raw]: sampling_offsets (heads x levels x points x 2) | attention logits
  *   ref        f32 [batch_size * num_query, ld_ref >= 2]: reference point (x, y) in [0, 1]

@@ -232,30 +232,35 @@ __global__ __launch_bounds__(kThreads) void daf_fused_rows(DfaArgs k) {
   const int g = ld_off / (C / G);
   const FEAT* featb = static_cast<const FEAT*>(k.feat) + (size_t)b * k.num_feat * C;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int kBatch = 4;   // samples (x 4 taps) requested before any is consumed: a trip of the loop is one memory round trip
   for (int lvl = wave; lvl < L; lvl += kWaves) {
     unsigned long long ma = m0, mb = m1;
     while (ma | mb) {
-      int i0, i1 = -1;
-      if (ma) { i0 = __builtin_ctzll(ma); ma &= ma - 1; } else { i0 = 64 + __builtin_ctzll(mb); mb &= mb - 1; }
-      if (ma) { i1 = __builtin_ctzll(ma); ma &= ma - 1; } else if (mb) { i1 = 64 + __builtin_ctzll(mb); mb &= mb - 1; }
-      const float x0 = i0 < 64 ? __shfl(l0.x, i0) : __shfl(l1.x, i0 - 64);
-      const float y0 = i0 < 64 ? __shfl(l0.y, i0) : __shfl(l1.y, i0 - 64);
-      const int cs0 = (i0 % cams) * L + lvl;
-      Tap4 t0, t1;
-      issue_taps(t0, featb + (size_t)k.scale_start[cs0] * C, k.spatial_shape[2 * cs0], k.spatial_shape[2 * cs0 + 1], C, x0, y0,
-                 ld_off);
-      const float wg0 = s_w[(i0 * L + lvl) * G + g];
-      float wg1 = 0.f;
-      if (i1 >= 0) {
-        const float x1 = i1 < 64 ? __shfl(l0.x, i1) : __shfl(l1.x, i1 - 64);
-        const float y1 = i1 < 64 ? __shfl(l0.y, i1) : __shfl(l1.y, i1 - 64);
-        const int cs1 = (i1 % cams) * L + lvl;
-        issue_taps(t1, featb + (size_t)k.scale_start[cs1] * C, k.spatial_shape[2 * cs1], k.spatial_shape[2 * cs1 + 1], C, x1,
-                   y1, ld_off);
-        wg1 = s_w[(i1 * L + lvl) * G + g];
+      int idx[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        idx[j] = -1;
+        if (ma) { idx[j] = __builtin_ctzll(ma); ma &= ma - 1; }
+        else if (mb) { idx[j] = 64 + __builtin_ctzll(mb); mb &= mb - 1; }
       }
-      accumulate(acc, t0, wg0);
-      if (i1 >= 0) accumulate(acc, t1, wg1);
+      Tap4 t[kBatch];
+      float wg[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        wg[j] = 0.f;
+        if (idx[j] >= 0) {   // wave-uniform
+          const int i = idx[j];
+          const float x = i < 64 ? __shfl(l0.x, i) : __shfl(l1.x, i - 64);
+          const float y = i < 64 ? __shfl(l0.y, i) : __shfl(l1.y, i - 64);
+          const int cs = (i % cams) * L + lvl;
+          issue_taps(t[j], featb + (size_t)k.scale_start[cs] * C, k.spatial_shape[2 * cs], k.spatial_shape[2 * cs + 1], C, x, y,
+                     ld_off);
+          wg[j] = s_w[(i * L + lvl) * G + g];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j)
+        if (idx[j] >= 0) accumulate(acc, t[j], wg[j]);
     }
   }
   __syncthreads();   // every wave has read the sums out of s_red

@@ -7,8 +7,8 @@
 //     sum_s a_s * bilinear(W_h x + b_h)(s)  =  W_h . [ sum_s a_s * bilinear(x)(s) ]  +  b_h * [ sum_s a_s * (valid tap weights of s) ]
 // (taps outside the map contribute zero to the left side -- the reference pads the PROJECTED map with zeros -- hence the
 // second bracket instead of a plain b_h). This kernel computes the two brackets: it samples the raw 256-channel token
-// rows per (query, head) and writes agg[q] = [8 heads x 256 | 8 tap-weight sums | pad] (2 112 floats); the projection
-// with W_h -- folded with output_proj into ONE [256 x 2 112] matrix on the host (plugin/dense.py: fold_msda_linear) --
+// rows per (query, head) and writes agg[q] = [8 heads x 256 | 8 tap-weight sums | pad] (2 176 floats); the projection
+// with W_h -- folded with output_proj into ONE [256 x 2 176] matrix on the host (plugin/dense.py: fold_msda_linear) --
 // is the small query-sized GEMM that follows (1.2 GFLOP instead of 11.8 + 0.15). Softmax of the attention logits,
 // reference point + offset / (W_l, H_l) (group_attn.py:181-201; csrc/rowops.hip msda_prep) ride in the prologue.
 //
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void msda_linear_fwd(
   *reinterpret_cast<f4*>(o + head * kC + coff) = lo;
   *reinterpret_cast<f4*>(o + head * kC + coff + 4) = hi;
   if ((lane & 31) == 0) o[kHeads * kC + head] = wsum;
-  if (tid >= kHeads && tid < 64) o[kHeads * kC + tid] = 0.f;   // pad columns of the 64-wide tail block
+  if (tid >= kHeads && tid < 128) o[kHeads * kC + tid] = 0.f;   // pad columns of the 128-wide tail block (the product's chunk)
 }
 
 }  // namespace
@@ -149,7 +149,7 @@ extern "C" int simpb_msda_linear_forward(float* agg, int ld_agg, const void* tok
   if (batch_size <= 0 || batch_size > 65535 || num_cams <= 0 || num_value <= 0 || num_query <= 0) return SIMPB_EINVAL;
   // compiled for the shipped layout (config :163-190: 8 heads x 32 channels, 4 levels, 4 points)
   if (num_heads != kHeads || channels * num_heads != kC || num_levels != kL || num_points != kP) return SIMPB_EINVAL;
-  if (ld_agg < kHeads * kC + 64 || (ld_agg & 3) || (reinterpret_cast<size_t>(agg) & 15) || ld_raw < 3 * kHeads * kLP ||
+  if (ld_agg < kHeads * kC + 128 || (ld_agg & 3) || (reinterpret_cast<size_t>(agg) & 15) || ld_raw < 3 * kHeads * kLP ||
       (ld_raw & 1) || (reinterpret_cast<size_t>(raw) & 7) || ld_ref < 2 || (reinterpret_cast<size_t>(tokens) & 15))
     return SIMPB_EINVAL;
   (void)hipGetLastError();

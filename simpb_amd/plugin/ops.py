@@ -281,14 +281,14 @@ def ms_deform_attn_grouped(value, spatial_shapes, level_start_index, sampling_lo
                                              attention_weights, query_cam)
 
 
-MSDA_LINEAR_WIDTH = 8 * 256 + 64   # row of simpb_msda_linear_forward: 8 heads x 256 channel sums | 8 tap-weight sums | pad
+MSDA_LINEAR_WIDTH = 8 * 256 + 128   # row of simpb_msda_linear_forward: 8 heads x 256 channel sums | 8 tap-weight sums | pad (a 128-deep chunk)
 
 
 def msda_linear(tokens, spatial_shapes, level_start_index, raw, reference_points, query_cam, m_live=None):
     """Camera-grouped deformable sampling of the RAW camera tokens (csrc/msda_lin.hip): what
     QueryGroupMultiScaleDeformableAttention computes between its value_proj and its output_proj, with value_proj moved
     behind the sampling by linearity. tokens f16 or f32 [bs, cams, Nv, 256]; raw [bs, Nq, 384] = sampling_offsets |
-    attention logits of [query | pos]; reference_points [bs, Nq, (1,) 2]; -> agg f32 [bs, Nq, 2112] (rows of capacity
+    attention logits of [query | pos]; reference_points [bs, Nq, (1,) 2]; -> agg f32 [bs, Nq, 2176] (rows of capacity
     slots are left unwritten: the product behind it skips them)."""
     _require_gpu(tokens, raw, reference_points, query_cam)
     if tokens.dtype not in (torch.float16, torch.float32) or not tokens.is_contiguous() or tokens.dim() != 4 or tokens.shape[-1] != 256:

@@ -48,8 +48,10 @@ DEFAULTS = dict(
     # DeformableFeatureAggregation: key points + projection + weight softmax inside the aggregation launch
     # (csrc/deform_agg_fused.hip). False: dfa_points + dfa_weights + the drop-in aggregation operator (three launches).
     fused_dfa=True,
-    # ... reading the f16 copy of the camera tokens the FPN leaves beside the fp32 rows (same bits, half the bytes)
-    dfa_f16_tokens=True,
+    # ... reading the f16 copy of the camera tokens the FPN leaves beside the fp32 rows (same numbers, half the bytes).
+    # Off: the launch is latency-bound at 900 anchors (26.5-27.4 us with f16 rows against 28.3-30.4 with fp32 rows,
+    # profiles/r03_*), so the fp32 rows of the operator's own contract (ops/src/deformable_aggregation.cpp:22-28) stay.
+    dfa_f16_tokens=False,
 )
 
 
