@@ -56,7 +56,7 @@ def parse():
                     help="frames start in pinned host memory and cross PCIe inside the timed step (async copy on the backbone "
                          "stream, beside the previous frame's decoder); default: inputs resident in HBM, as `value` requires")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=21, help="frames of the CPU baseline leg: 1 cold + the warm frames that are timed")
     return ap.parse_args()
 
 
@@ -103,6 +103,16 @@ class KernelMeter:
                                             small=anchor.numel() + learn.numel())))
             return out
 
+        def msda_lin(tokens, ss, lsi, raw, ref, qcam, m_live=None):
+            out = self.lin_orig(tokens, ss, lsi, raw, ref, qcam, m_live)
+            if self.enabled:
+                self.msda_calls.append(((raw.shape[0], raw.shape[1], 8, 4, 4, 2), 256, qcam,
+                                        dict(tok_bytes=tokens.element_size(), row=out.shape[-1], raw=raw.shape[-1])))
+            return out
+
+        from simpb_amd.plugin import ops as _ops
+        self.ops, self.lin_orig = _ops, _ops.msda_linear
+        _ops.msda_linear = msda_lin
         self.blocks.DAF = daf
         self.blocks.dfa_fused = fused
         self.group_attn.ms_deform_attn_grouped = msda
@@ -111,6 +121,7 @@ class KernelMeter:
     def __exit__(self, *exc):
         self.blocks.DAF, self.group_attn.ms_deform_attn_grouped = self.daf_orig, self.msda_orig
         self.blocks.dfa_fused = self.fused_orig
+        self.ops.msda_linear = self.lin_orig
         self.lib.simpb_timing_enable(0)
 
     def start(self):
@@ -154,13 +165,22 @@ class KernelMeter:
         d = self._durations(self.MSDA)
         if d and len(d) == len(self.msda_calls):
             nbytes = 0.0
-            for (bs, nq, heads, lvls, pts, _), ch, qcam in self.msda_calls:
-                # per query: heads*lvls*pts samples * 4 taps * ch * 4 B + loc + attn + out; capacity slots
-                # outside every camera group (query_cam < 0) are skipped by the kernel and not counted
+            kernel, s_v = "msda_grouped_fwd", 4
+            for call in self.msda_calls:
+                (bs, nq, heads, lvls, pts, _), ch, qcam = call[:3]
+                # capacity slots outside every camera group (query_cam < 0) are skipped by the kernel and not counted
                 nq = int((qcam >= 0).sum())
-                nbytes += bs * nq * (heads * lvls * pts * 4 * ch * 4 + heads * lvls * pts * 3 * 4 + heads * ch * 4)
+                if len(call) > 3:
+                    # sampling of the RAW tokens (csrc/msda_lin.hip: value_proj moved behind the sampling): per query
+                    # heads*lvls*pts samples * 4 taps * 256 channels * token bytes + offsets|logits row + the 8 x 256 + tail row written
+                    info = call[3]
+                    kernel, s_v = "msda_linear_fwd", info["tok_bytes"]
+                    nbytes += bs * nq * (heads * lvls * pts * 4 * ch * s_v + info["raw"] * 4 + 8 + info["row"] * 4)
+                else:
+                    # per query: heads*lvls*pts samples * 4 taps * ch * 4 B + loc + attn + out
+                    nbytes += bs * nq * (heads * lvls * pts * 4 * ch * 4 + heads * lvls * pts * 3 * 4 + heads * ch * 4)
             n = len(d)
-            out["msda"] = dict(kernel="msda_grouped_fwd", secs=sum(d) / n, nbytes=nbytes / n, launches=n)
+            out["msda"] = dict(kernel=kernel, secs=sum(d) / n, nbytes=nbytes / n, launches=n, feature_bytes_per_element=s_v)
         return out
 
 
@@ -193,8 +213,10 @@ def cpu_baseline(args):
     bounded sample of the same workload. kind = 'port': the reference itself cannot travel."""
     from oracle import simpb_ref as R
     from simpb_amd import configs, plugin, synth
-    # the box's CPU share, not the machine's core count: a one-GPU box is entitled to 16 workers
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    # the box's CPU share (its affinity mask; a one-GPU box is entitled to 16 workers), not the machine's core count:
+    # a thread pool sized to os.cpu_count() on a shared host oversubscribes the share and runs slower
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(share, 16)
     torch.set_num_threads(cores)
     cfg = configs.simpb_plus(depth=args.depth, input_shape=tuple(args.image_wh), anchor=synth.anchors(900))
     model = plugin.build_detector(cfg["model"]).eval()
@@ -214,16 +236,42 @@ def cpu_baseline(args):
             times.append(time.perf_counter() - t0)
     warm = times[1:] or times
     return dict(value=len(warm) / sum(warm), unit="frames/s", cores=cores, kind="port",
-                sample=f"bounded sample (not BASELINE.md's 50-frame protocol: a frame takes ~1 s here): {len(warm)} warm frame(s) "
-                       f"after 1 cold, bs=1, oracle head fp32 + PyTorch CPU ResNet{args.depth}+FPN fp32, "
-                       f"torch threads={cores}")
+                ms_per_frame_min=min(warm) * 1e3, ms_per_frame_max=max(warm) * 1e3,
+                sample=f"bounded sample of the same workload: {len(warm)} warm frame(s) after 1 cold (BASELINE.md's protocol is 50; a "
+                       f"frame takes ~1 s here), bs=1, oracle head fp32 + PyTorch CPU ResNet{args.depth}+FPN fp32, torch threads={cores} "
+                       f"(os.cpu_count()={os.cpu_count()}, affinity mask={share}: the threads are the box's CPU share, capped at 16)")
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, as the child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` (one process per GPU),
+    BEFORE this process has touched the GPU, and exit with its status. The child's rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if have < args.gpus and os.environ.get("SIMPB_BENCH_DEVICE") is None:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s); refusing to report a {args.gpus}-GPU "
+                         "number from fewer (set SIMPB_BENCH_DEVICE only for the one-GPU rehearsal)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:   # never label a run with a GPU count it did not use
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -266,7 +314,10 @@ def main():
             use_graph=not args.eager))
     runner = runners[0]
     # N > 1: the fixed-shape device record of every stream to every rank, one all-gather per frame on a side stream
-    gather = DetectionGather(args.streams * args.bs, runner.head.decoder.num_output, device) if dist is not None else None
+    gather = None
+    if dist is not None:   # 2D rows: anchors x cameras can never be exceeded, and every rank must use the same shape
+        gather = DetectionGather(args.streams * args.bs, runner.head.decoder.num_output, device,
+                                 rows2d=runner.head.num_anchor * runner.head.num_cams)
 
     def step(f, force_eager=False):
         if len(runners) == 1:
@@ -282,7 +333,8 @@ def main():
         if results is None:  # pipelined runner, very first call: nothing decoded yet
             return None
         if gather is not None:
-            gather.submit([r.last_rec3d for r in runners], [r.s_head for r in runners if hasattr(r, "s_head")])
+            gather.submit([r.last_rec3d for r in runners], [r.s_head for r in runners if hasattr(r, "s_head")],
+                          records2d=[r.last_rec2d for r in runners])
             for r in runners:
                 r.rec_consumed = gather.done
         return results
@@ -362,7 +414,8 @@ def main():
             return r
 
         roof = roofline(ksum["daf"], f"3D deformable aggregation ({ksum['daf']['kernel']}, {ksum['daf'].get('feature_bytes_per_element', 4)} B per token element)") if "daf" in ksum else None
-        roof2 = roofline(ksum["msda"], "camera-grouped MSDeformAttn sampling over the value_proj output") if "msda" in ksum else None
+        roof2 = roofline(ksum["msda"], "camera-grouped MSDeformAttn sampling of the raw camera tokens (value_proj applied behind the sampling)"
+                         if ksum["msda"]["kernel"] == "msda_linear_fwd" else "camera-grouped MSDeformAttn sampling over the value_proj output") if "msda" in ksum else None
         line = {
             "metric": "frames/sec (6-cam sample) + MSDeformAttn HBM GB/s, R50 704x256 @1/2/4/8 GPU",
             "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -370,7 +423,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"simpb_nus_r{args.depth}_img_{args.image_wh[0]}x{args.image_wh[1]}: 6-cam frames, "
                                    f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, {args.streams} stream(s) x bs={args.bs} per GPU, temporal",
-                       "streams_per_gpu": args.bs * args.streams, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "head_dtype": "f32 throughout; value_proj on the FP16 matrix cores with split operands and f32 accumulators (fp32-grade: same 2e-5 bound vs float64 as the exact kernel)", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
+                       "streams_per_gpu": args.bs * args.streams, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "head_dtype": "f32 throughout (exact fp32 matrix instructions); the camera tokens are the fp16 backbone's output, sampled as they are and accumulated in f32", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
                        if world > 1 else "single GPU", "inputs": "pinned host frames, H2D inside the timed step" if args.h2d else "resident in HBM",
                        "fp16_matrix_step": "2 x v_mfma_f32_32x32x8f16 (csrc/mfma_f16.h)", "num_query2d_last_frame": n2, "frame_runner": mode},
             "roofline": roof, "roofline_msda": roof2,

@@ -74,29 +74,58 @@ def gather_detections(record, out=None, group=None):
     return out
 
 
+RECORD2D_WIDTH = 8   # box xyxy (4) + score + label + rank of its 3D box in the frame's record (-1: none) + camera (-1: pad)
+
+
+def unpack_detections2d(record2d):
+    """f32 [..., rows, 8] (the 2D device record csrc/decode.hip writes, padded with camera = -1 rows) -> list (one per
+    leading index, flattened) of dicts boxes_2d / scores_2d / labels_2d / camidx_2d / rank3d of the rows that are associated
+    with a kept 3D box: what decoder.py:176-251 puts into the result dict next to the 3D fields."""
+    record2d = record2d.cpu() if torch.is_tensor(record2d) else torch.from_numpy(np.asarray(record2d))
+    out = []
+    for r in record2d.reshape(-1, record2d.shape[-2], record2d.shape[-1]):
+        keep = (r[:, 7] >= 0) & (r[:, 6] >= 0)
+        r = r[keep]
+        out.append(dict(boxes_2d=r[:, :4], scores_2d=r[:, 4], labels_2d=r[:, 5].long(), camidx_2d=r[:, 7], rank3d=r[:, 6].long()))
+    return out
+
+
 class DetectionGather:
-    """The per-frame exchange: every rank's device records [streams, num_output, 15] to every rank, one
-    all_gather_into_tensor per frame, off the compute streams.
+    """The per-frame exchange: every rank's device records to every rank -- the 3D record [streams, num_output, 15] and,
+    with rows2d > 0, the 2D record [streams, rows2d, 8] (decoder.py:230-251 returns boxes_2d / scores_2d / labels_2d /
+    camidx_2d beside the 3D fields; apis/test.py:49-119 collects the whole dict) -- in ONE all_gather_into_tensor per
+    frame, off the compute streams. rows2d is a fixed exchange capacity equal on every rank (num_anchor x num_cams can
+    never be exceeded: an anchor holds at most one slot per camera); a runner's 2D record is copied into its leading rows
+    and the rest stay pad rows (camera = -1).
 
     The send and receive buffers are persistent and owned by the side stream, so no allocator block crosses streams;
     the records handed to submit() are read on the side stream after it has waited for their producer streams and are
-    marked with record_stream, so the caching allocator cannot hand their blocks out while the copy is pending. The
-    host never waits inside submit(); result() waits for the last exchange only."""
+    marked with record_stream, so the caching allocator cannot hand their blocks out while the copy is pending. Records
+    that live in a replayed graph's memory are protected by the runners: they make every graph that may write that memory
+    wait for `done` (runner.rec_consumed). The host never waits inside submit(); result() waits for the last exchange."""
 
-    def __init__(self, streams, num_output, device, group=None):
+    def __init__(self, streams, num_output, device, group=None, rows2d=0):
         self.device = torch.device(device)
         self.group = group
         self.cuda = self.device.type == "cuda"
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
-        self.send = torch.zeros(streams, num_output, RECORD_WIDTH, device=self.device)
-        self.recv = torch.zeros(self.world, streams, num_output, RECORD_WIDTH, device=self.device)
+        self.n3, self.rows2d = num_output * RECORD_WIDTH, int(rows2d)
+        width = self.n3 + self.rows2d * RECORD2D_WIDTH
+        self.send_buf = torch.zeros(streams, width, device=self.device)
+        self.recv_buf = torch.zeros(self.world, streams, width, device=self.device)
+        self.send = self.send_buf[:, :self.n3].unflatten(1, (num_output, RECORD_WIDTH))
+        self.recv = self.recv_buf[..., :self.n3].unflatten(2, (num_output, RECORD_WIDTH))
+        self.send2d = self.send_buf[:, self.n3:].unflatten(1, (self.rows2d, RECORD2D_WIDTH)) if self.rows2d else None
+        self.recv2d = self.recv_buf[..., self.n3:].unflatten(2, (self.rows2d, RECORD2D_WIDTH)) if self.rows2d else None
+        if self.rows2d:
+            self.send2d[..., 6:8] = -1.0   # pad rows: no 3D partner, no camera
         self.done = None
         self.frames = 0
         # rehearsal of N > 1 on one GPU box (bench.py --backend gloo): gloo has no device all-gather, stage through the host
         self.via_host = self.cuda and self.world > 1 and dist.get_backend(group) == "gloo"
 
-    def _exchange(self, records):
+    def _exchange(self, records, records2d):
         at = 0
         for r in records:
             n = r.shape[0]
@@ -106,30 +135,44 @@ class DetectionGather:
             at += n
         if at != self.send.shape[0]:
             raise ValueError(f"{at} stream records submitted, {self.send.shape[0]} expected")
+        if self.rows2d:
+            if records2d is None:
+                raise ValueError("this exchange carries the 2D records as well: pass records2d")
+            at = 0
+            for r in records2d:
+                n, rows = r.shape[:2]
+                if r.shape[2] != RECORD2D_WIDTH or rows > self.rows2d:
+                    raise ValueError(f"2D record {tuple(r.shape)} does not fit [*, <= {self.rows2d}, {RECORD2D_WIDTH}]")
+                self.send2d[at:at + n, :rows].copy_(r, non_blocking=True)   # (rows past it are pad rows and stay so: capacities only grow)
+                at += n
+            if at != self.send.shape[0]:
+                raise ValueError(f"{at} 2D stream records submitted, {self.send.shape[0]} expected")
+        flat = self.recv_buf.view(-1, self.recv_buf.shape[-1])
         if self.world > 1 and self.via_host:
-            host = torch.empty(self.recv.shape, dtype=self.recv.dtype)
-            dist.all_gather_into_tensor(host.view((-1,) + tuple(self.send.shape[1:])), self.send.cpu(), group=self.group)
-            self.recv.copy_(host)
+            host = torch.empty(flat.shape, dtype=flat.dtype)
+            dist.all_gather_into_tensor(host, self.send_buf.cpu(), group=self.group)
+            flat.copy_(host)
         elif self.world > 1:
-            dist.all_gather_into_tensor(self.recv.view((-1,) + tuple(self.send.shape[1:])), self.send, group=self.group)
+            dist.all_gather_into_tensor(flat, self.send_buf, group=self.group)
         else:
-            self.recv[0].copy_(self.send, non_blocking=True)
+            self.recv_buf[0].copy_(self.send_buf, non_blocking=True)
 
-    def submit(self, records, producers=()):
-        """records: device tensors [bs_i, num_output, 15] of this rank's runners, in stream order; producers: the
-        streams they were written on (the side stream waits for them; the current stream is always waited for)."""
+    def submit(self, records, producers=(), records2d=None):
+        """records: device tensors [bs_i, num_output, 15] of this rank's runners, in stream order (records2d: their 2D
+        records [bs_i, rows_i, 8]); producers: the streams they were written on (the side stream waits for them; the
+        current stream is always waited for)."""
         if not self.cuda:
-            self._exchange(records)
+            self._exchange(records, records2d)
             self.frames += 1
             return
         self.side.wait_stream(torch.cuda.current_stream(self.device))
         for s in producers:
             self.side.wait_stream(s)
         with torch.cuda.stream(self.side):
-            self._exchange(records)
+            self._exchange(records, records2d)
             self.done = torch.cuda.Event()
             self.done.record(self.side)
-        for r in records:
+        for r in list(records) + list(records2d or ()):
             r.record_stream(self.side)
         self.frames += 1
 
@@ -138,3 +181,9 @@ class DetectionGather:
         if self.done is not None:
             self.done.synchronize()
         return self.recv
+
+    def result2d(self):
+        """[world, streams, rows2d, 8] of the last submitted frame (pad rows: camera = -1)."""
+        if self.done is not None:
+            self.done.synchronize()
+        return self.recv2d

@@ -51,7 +51,11 @@ class FrameRunner:
         self.host3d = self.host2d = self.host_flag = None
         self.stats = dict(eager=0, replay=0, overflow=0)
         self.last_rec3d = None      # device record f32 [bs, num_output, 15] of the frame last returned (dist.DetectionGather)
-        self.rec_consumed = None    # event after which that record may be overwritten (set by its consumer, if any)
+        self.last_rec2d = None      # ... and its 2D record f32 [bs, capacity, 8]
+        # event after which those records may be overwritten (set by their consumer, if any). The records of a replayed
+        # frame live in graph memory: EVERY graph of this runner that may write that memory waits for it before its next
+        # replay (the decoder graphs and, in SplitPipelinedRunner, part A, which shares the pool of part B)
+        self.rec_consumed = None
 
     # ------------------------------------------------------------------ per-frame host work
     def _stage(self, img, metas):
@@ -128,6 +132,8 @@ class FrameRunner:
             with torch.cuda.graph(self.graph):
                 self.outputs = self._frame(dmetas, aug)
         if warm and self.graph is not None and not force_eager:
+            if self.rec_consumed is not None:
+                torch.cuda.current_stream().wait_event(self.rec_consumed)
             self.graph.replay()
             rec = self.outputs
             self.stats["replay"] += 1
@@ -144,7 +150,7 @@ class FrameRunner:
             rec = self._frame(dmetas, aug)
             self.stats["eager"] += 1
             rec3d, rec2d, overflow = self._read_back(*rec)
-        self.last_rec3d = rec[0]
+        self.last_rec3d, self.last_rec2d = rec[0], rec[1]
         self.prev_metas = dict(img_metas=metas["img_metas"])
         self.head.instance_bank.metas = self.prev_metas
         results = SparseBox3DDecoder.decode_static_host(rec3d.numpy(), rec2d.numpy(), self.head.num_cams)
@@ -341,7 +347,7 @@ class PipelinedRunner(FrameRunner):
                 h = self.host[job["slot"]]
             for b in behind:
                 self.queue.append(self._enqueue_decoder(b["slot"], b["metas"], b["prev"], True))
-        self.last_rec3d = job["rec"][0]
+        self.last_rec3d, self.last_rec2d = job["rec"][0], job["rec"][1]
         self.prev_metas = dict(img_metas=job["metas"]["img_metas"])
         results = SparseBox3DDecoder.decode_static_host(h[0].numpy(), h[1].numpy(), self.head.num_cams)
         return [{"img_bbox": r} for r in results]
@@ -500,6 +506,8 @@ class SplitPipelinedRunner(PipelinedRunner):
             self._stage_slot(slot, metas, prev, self.s_pre)
             with torch.cuda.stream(self.s_pre):
                 self.s_pre.wait_event(self.bb_done[slot])
+                if self.rec_consumed is not None:   # part A shares part B's pool: the records may sit in memory A reuses
+                    self.s_pre.wait_event(self.rec_consumed)
                 self.pre_graph[slot].replay()
                 self.pre_done[slot].record(self.s_pre)
             with torch.cuda.stream(self.s_head):

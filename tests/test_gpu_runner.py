@@ -295,6 +295,44 @@ def test_config3_eight_streams_per_gpu_vs_golden(split):
             compare_result(out[f][0]["img_bbox"], g, f"f{f}.res0.")
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_gathered_record_survives_two_more_steps_before_it_is_read(split):
+    """The exchange's asynchronous window: the device records (3D and 2D) of the frame step(t) returned are SUBMITTED to
+    dist.DetectionGather without waiting for the exchange, the runner goes on for two more steps (replayed graphs: part
+    A of frame t+2 shares part B's memory pool and is enqueued on the other stream), and only then the gathered record is
+    read: it must still be frame t's, bit for bit. Each runner makes every graph that may write the record's memory wait
+    for `rec_consumed`; here the side stream is held up behind a long kernel so that the copy really is still pending
+    when those graphs are enqueued."""
+    from simpb_amd.dist import DetectionGather, unpack_detections, unpack_detections2d
+    g = load_golden("head_r50.npz")
+    spec = spec_of(g)
+    model, runner = _golden_pipelined_runner(spec, split)
+    gather = DetectionGather(1, 300, torch.device("cuda"), rows2d=900 * 6)
+    spin = torch.empty(64 * 1024 * 1024, device="cuda")
+    frames, pending, checked = 30, [], 0
+    for f in range(frames):
+        model.stage(f)
+        torch.cuda.synchronize()
+        res = runner.step(runner.img, synth.frame_metas(1, f, spec["image_wh"]))
+        if pending and f - pending[0][0] >= 2:     # two steps later: read what was submitted then
+            _, want = pending.pop(0)
+            rec = unpack_detections(gather.result()[0])
+            assert torch.equal(rec["boxes_3d"][0], want["boxes_3d"]) and torch.equal(rec["scores_3d"][0], want["scores_3d"])
+            assert torch.equal(rec["instance_ids"][0], want["instance_ids"])
+            got2d = unpack_detections2d(gather.result2d()[0])[0]
+            assert torch.equal(got2d["boxes_2d"], want["boxes_2d"]) and torch.equal(got2d["scores_2d"], want["scores_2d"])
+            assert torch.equal(got2d["labels_2d"], want["labels_2d"]) and torch.equal(got2d["camidx_2d"], want["camidx_2d"])
+            checked += 1
+        if res is not None and not pending and f >= 8:   # replayed frames only, one exchange in flight at a time
+            with torch.cuda.stream(gather.side):   # keep the side stream busy: the copy below stays pending for a while
+                for _ in range(20):
+                    spin.add_(1.0)
+            gather.submit([runner.last_rec3d], [runner.s_head], records2d=[runner.last_rec2d])
+            runner.rec_consumed = gather.done
+            pending.append((f, res[0]["img_bbox"]))
+    assert checked >= 5 and runner.stats["replay"] >= frames - 10, (checked, runner.stats)
+
+
 class _ReplayModel(torch.nn.Module):
     """Detector stand-in that serves recorded feature maps from fixed-address buffers."""
 
