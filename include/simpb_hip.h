@@ -156,6 +156,21 @@ int simpb_linear_f16x3(float* y, const float* x, const void* weight_hi, const vo
 int simpb_linear_f16in_split(float* y, const void* x_f16, const void* weight_hi, const void* weight_lo, const float* bias,
                              int M, int N, int K, void* stream);
 
+/* ResNet stem in one launch: conv 7x7 / stride 2 / padding 3 (3 -> 64, BN folded) + bias + ReLU + max_pool 3x3 / stride 2 /
+ * padding 1 = mmdet ResNet.forward's maxpool(relu(bn1(conv1(x)))) (config :79-99 after tools/fuse_conv_bn.py:10-48).
+ *   img_nhwc4      f16 [num_images, height, width, 4]  RGB + a zero channel (simpb_image_to_nhwc4_f16 makes it)
+ *   weight_packed  f16 [28][2][64][4]: entry [ky * 4 + g][kb][n][c] = weight[n][c][ky][2 g + kb] (0 for c = 3 or tap 7)
+ *   bias f16 [64];  out f16 [num_images, Hp, Wp, 64] (NHWC), Hp = ((height + 6 - 7) / 2 + 1 + 2 - 3) / 2 + 1
+ * Conv results are rounded to f16 before bias / ReLU / maximum (fp32), i.e. what a stored f16 conv map + the fused
+ * epilogue (simpb_bias_relu_maxpool_nhwc_f16) give. out_channels must be 64. */
+int simpb_stem_conv7x7_pool_f16(void* out, const void* img_nhwc4, const void* weight_packed, const void* bias,
+                                int num_images, int height, int width, int out_channels, void* stream);
+
+/* f32 image with arbitrary element strides [num_images, channels <= 3, height, width] -> f16 [N, H, W, 4], missing
+ * channels zero: the cast + channels_last copy in front of the stem. */
+int simpb_image_to_nhwc4_f16(void* out, const float* img, long long stride_n, long long stride_c, long long stride_h,
+                             long long stride_w, int num_images, int channels, int height, int width, void* stream);
+
 /* Grouped small GEMM of the decoder: up to 4 independent problems per launch, each
  *   y[M, 0:N] (row stride ldy) = relu?( [x0 | x1 | ...][M, K] . w[N, K]^T (row stride ldw) + bias[N] )
  * where x is given as up to 4 column segments (pointer, row stride, width; widths sum to K). This is

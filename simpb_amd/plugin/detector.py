@@ -121,9 +121,21 @@ class ResNet(BaseModule):
             self.add_module(name, nn.Sequential(*layers))
             self.res_layers.append(name)
 
+    def _stem_kernel_ok(self, x):
+        c1, mp = self.conv1, self.maxpool
+        return (routes.R.stem_kernel and getattr(self, "fused_epilogue", False) and x.is_cuda and x.dtype == torch.float32
+                and tuple(c1.weight.shape) == (64, 3, 7, 7) and c1.stride == (2, 2) and c1.padding == (3, 3) and c1.bias is not None
+                and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1 and mp.dilation == 1 and not mp.ceil_mode)
+
     def forward(self, x):
-        if getattr(self, "fused_epilogue", False) and x.is_cuda and x.dtype == torch.float16:
+        if self._stem_kernel_ok(x):
+            # the whole stem -- cast, 7x7 convolution, bias, ReLU, max-pool -- in two launches of our own (csrc/stem.hip)
+            from .ops import stem_conv_pool
+            x = stem_conv_pool(x, self.conv1.weight, self.conv1.bias)
+        elif getattr(self, "fused_epilogue", False) and x.is_cuda and x.dtype in (torch.float16, torch.float32):
             from .ops import bias_act_, bias_relu_maxpool
+            if x.dtype == torch.float32:
+                x = x.half().contiguous(memory_format=torch.channels_last)
             x = F.conv2d(x, self.conv1.weight, None, self.conv1.stride, self.conv1.padding)
             mp = self.maxpool
             if (routes.R.stem_epilogue_kernel and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1 and mp.dilation == 1
@@ -302,8 +314,8 @@ class SimPB(BaseModule):
             img = img.flatten(end_dim=1)
         else:
             num_cams = 1
-        if self.fp16_enabled:
-            img = img.half().contiguous(memory_format=torch.channels_last)
+        if self.fp16_enabled and not (img.dtype == torch.float32 and getattr(self.img_backbone, "_stem_kernel_ok", lambda t: False)(img)):
+            img = img.half().contiguous(memory_format=torch.channels_last)   # (the stem kernel route casts inside its own launch)
         feature_maps = self.img_backbone(img)
         biases = None
         if self.img_neck is not None:

@@ -510,6 +510,42 @@ def conv3x3_nhwc(x, weight, bias, relu=True, stride=1, tokens=None, variant=0):
     return y
 
 
+def _stem_weight_packed(weight):
+    """f16 [28][2][64][4] fragment order of csrc/stem.hip from the stem's [64, 3, 7, 7] weight, cached on the tensor."""
+    tag = (weight.data_ptr(), weight._version, str(weight.device))
+    hit = getattr(weight, "_simpb_stem_pack", None)
+    if hit is None or hit[0] != tag:
+        with torch.no_grad():
+            w = weight.detach().float()                                  # [n, c, ky, kx]
+            full = torch.zeros(64, 4, 7, 8, device=w.device)
+            full[:, :3, :, :7] = w
+            # [ky][g][kb][n][c] with kx = 2 g + kb
+            pack = full.reshape(64, 4, 7, 4, 2).permute(2, 3, 4, 0, 1).contiguous().half()
+        hit = (tag, pack)
+        weight._simpb_stem_pack = hit
+    return hit[1]
+
+
+def stem_conv_pool(img, weight, bias):
+    """maxpool3x3s2p1(relu(conv7x7s2p3(half(img)) + bias)) in one launch (csrc/stem.hip) behind a cast pass of our own. img f32
+    [N, 3, H, W] (any strides); weight f16/f32 [64, 3, 7, 7]; bias [64] -> f16 [N, 64, Hp, Wp] channels_last."""
+    _require_gpu(img, weight, bias)
+    n, c, h, w = img.shape
+    if img.dtype != torch.float32 or c != 3 or tuple(weight.shape) != (64, 3, 7, 7) or bias.numel() != 64 or h < 8 or w < 8:
+        raise ValueError("stem_conv_pool: f32 [N, 3, H, W] image, [64, 3, 7, 7] weight, 64 biases")
+    lib = _lib.lib()
+    x4 = torch.empty(n, h, w, 4, device=img.device, dtype=torch.float16)
+    _lib.check(lib.simpb_image_to_nhwc4_f16(_ptr(x4), _ptr(img), img.stride(0), img.stride(1), img.stride(2), img.stride(3), n, c, h, w,
+                                            _stream()), "simpb_image_to_nhwc4_f16")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    hp, wp = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    out = torch.empty((n, 64, hp, wp), device=img.device, dtype=torch.float16, memory_format=torch.channels_last)
+    b16 = bias if bias.dtype == torch.float16 and bias.is_contiguous() else bias.half().contiguous()
+    _lib.check(lib.simpb_stem_conv7x7_pool_f16(_ptr(out), _ptr(x4), _ptr(_stem_weight_packed(weight)), _ptr(b16), n, h, w, 64,
+                                               _stream()), "simpb_stem_conv7x7_pool_f16")
+    return out
+
+
 def topk_rows(scores, k):
     """(values [bs, k] sorted descending, indices i64 [bs, k]) of scores f32 [bs, n]: torch.topk(sorted=True)
     semantics with ties broken towards the lower index, one launch (csrc/rowops.hip)."""
