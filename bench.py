@@ -333,7 +333,7 @@ def main():
         if results is None:  # pipelined runner, very first call: nothing decoded yet
             return None
         if gather is not None:
-            gather.submit([r.last_rec3d for r in runners], [r.s_head for r in runners if hasattr(r, "s_head")],
+            gather.submit([r.last_rec3d for r in runners], [r.s_rec for r in runners if hasattr(r, "s_rec")],
                           records2d=[r.last_rec2d for r in runners])
             for r in runners:
                 r.rec_consumed = gather.done

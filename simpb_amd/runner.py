@@ -183,6 +183,7 @@ class PipelinedRunner(FrameRunner):
         prio = getattr(self, "STREAM_PRIORITIES", (0, -1))
         self.s_bb = torch.cuda.Stream(device=dev, priority=prio[0])
         self.s_head = torch.cuda.Stream(device=dev, priority=prio[1])
+        self.s_rec = self.s_head            # the stream the detection records are written on (for their consumers)
         self.imgs = [self.img, torch.zeros_like(self.img)]
         self.fm = [None, None]              # feature maps of the frame last produced into each slot
         self.bb_graph = [None, None]

@@ -279,7 +279,7 @@ def test_config3_eight_streams_per_gpu_vs_golden(split):
         for i in live:
             outs[i].append(pairs[i][1].collect())
         if len(live) == n and all(o[-1] is not None for o in outs):
-            gather.submit([pairs[i][1].last_rec3d for i in range(n)], [pairs[i][1].s_head for i in range(n)])
+            gather.submit([pairs[i][1].last_rec3d for i in range(n)], [pairs[i][1].s_rec for i in range(n)])
             for i in range(n):
                 pairs[i][1].rec_consumed = gather.done
             rec = unpack_detections(gather.result()[0])
@@ -327,7 +327,7 @@ def test_gathered_record_survives_two_more_steps_before_it_is_read(split):
             with torch.cuda.stream(gather.side):   # keep the side stream busy: the copy below stays pending for a while
                 for _ in range(20):
                     spin.add_(1.0)
-            gather.submit([runner.last_rec3d], [runner.s_head], records2d=[runner.last_rec2d])
+            gather.submit([runner.last_rec3d], [runner.s_rec], records2d=[runner.last_rec2d])
             runner.rec_consumed = gather.done
             pending.append((f, res[0]["img_bbox"]))
     assert checked >= 5 and runner.stats["replay"] >= frames - 10, (checked, runner.stats)

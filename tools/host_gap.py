@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simpb_amd import configs, plugin, synth  # noqa: E402
 from simpb_amd.plugin.detection3d import SparseBox3DDecoder  # noqa: E402
-from simpb_amd.runner import PipelinedRunner  # noqa: E402
+from simpb_amd.runner import PipelinedRunner, SplitPipelinedRunner  # noqa: E402
 
 wh = (704, 256)
 cfg = configs.simpb_plus(anchor=synth.anchors(900))
@@ -19,7 +19,7 @@ model = plugin.build_detector(cfg["model"]).eval()
 synth.load_procedural(model)
 model = model.cuda().fuse_conv_bn().half_backbone()
 torch.backends.cudnn.benchmark = True
-r = PipelinedRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"))
+r = (SplitPipelinedRunner if "--split" in sys.argv else PipelinedRunner)(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"))
 imgs = [synth.images(1, f, wh).cuda() for f in range(4)]
 metas = [synth.frame_metas(1, f, wh) for f in range(140)]
 for f in range(20):

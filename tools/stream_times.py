@@ -32,7 +32,7 @@ if "--prio" in sys.argv:   # --prio BB HEAD: stream priorities of the backbone /
     print("stream priorities (backbone, decoder):", PipelinedRunner.STREAM_PRIORITIES, torch.cuda.Stream.priority_range(), flush=True)
 r = PipelinedRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"))
 DEC_ONLY = "--dec-only" in sys.argv   # for rocprofv3 --kernel-trace: decoder graph replays with nothing beside them
-if len(sys.argv) > 1 and not DEC_ONLY and "--co" not in sys.argv and "--prio" not in sys.argv:
+if len(sys.argv) > 1 and not DEC_ONLY and "--bb-only" not in sys.argv and "--co" not in sys.argv and "--prio" not in sys.argv:
     # --bb-drop N: the backbone stream loses one group of 8 CUs in every N groups (in every XCD, whichever way CU indices
     # map to XCDs); the decoder stream keeps the whole chip
     import ctypes
@@ -123,6 +123,10 @@ if "--co" in sys.argv:
     sys.exit(0)
 if DEC_ONLY:
     dec()
+    torch.cuda.synchronize()
+    sys.exit(0)
+if "--bb-only" in sys.argv:   # for rocprofv3 --kernel-trace: backbone graph replays with nothing beside them
+    bb()
     torch.cuda.synchronize()
     sys.exit(0)
 for name, fn in (("backbone graph alone", bb), ("decoder graph alone", dec), ("both streams side by side", both)):
