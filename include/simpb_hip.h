@@ -375,11 +375,27 @@ int simpb_bank_update(float* feature_out, float* anchor_out, long long* instance
                       const float* feature, const float* anchor, const float* cls, const float* cached_feature,
                       const float* cached_anchor, const unsigned char* mask, int batch_size, int num_anchors,
                       int num_classes, int num_temp, int embed_dims, void* stream);
+/* simpb_bank_update in its two steps, for callers that can rank early: the ranking depends on the first decoder layer's
+ * classification only, not on the bank, so a caller overlapping frames computes it beside the previous frame's decoder
+ * (runner.SplitPipelinedRunner) and only the merge waits for the bank. The merge can also carry the anchor embeddings
+ * (embed_out / embed [bs, A, E] / cached_embed [bs, T, E], all NULL = absent): embedding rows follow their anchor rows, which
+ * replaces the encoder launch behind the update (models/simpb_head.py:621-622). hold (i32 [num_hold], may be NULL): when
+ * any is set the instance_id reset of masked-out streams is skipped (the frame is going to be re-run). sticky (device i32,
+ * may be NULL) chains the hold over frames decoded before the host has seen their predecessor's flags: simpb_bank_cache
+ * writes "held back" (0 / 1) into it at the end of a frame, and a set word holds the NEXT frame's update and commit back
+ * like one of its own flags. */
+int simpb_bank_update_rank(int* index_scratch, const float* cls, int batch_size, int num_anchors, int num_classes,
+                           int num_temp, void* stream);
+int simpb_bank_update_merge(float* feature_out, float* anchor_out, float* embed_out, long long* instance_id, const int* index,
+                            const float* feature, const float* anchor, const float* embed, const float* cached_feature,
+                            const float* cached_anchor, const float* cached_embed, const unsigned char* mask, const int* hold,
+                            int num_hold, const int* sticky, int batch_size, int num_anchors, int num_temp, int embed_dims,
+                            int pos_embed_dims, void* stream);
 int simpb_bank_cache(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
                      long long* prev_id, long long* ids_out, int* index_scratch, const float* feature, const float* anchor,
                      const float* cls, int batch_size, int num_anchors, int num_classes, int num_temp, int embed_dims,
                      int has_previous, float confidence_decay, int has_threshold, float threshold, const int* hold,
-                     int num_hold, void* stream);
+                     int num_hold, int* sticky, void* stream);
 
 /* Fixed-shape detection records of SparseBox3DDecoder.decode_with2d (models/detection3d/decoder.py:124-252).
  * 3D (:133-167 with squeezed classes + decode_box :23-34), one workgroup per sample:

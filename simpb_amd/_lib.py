@@ -39,7 +39,9 @@ SIGNATURES = {
     "simpb_mlp_chain_forward": ([_P, _P], _I),
     "simpb_bank_get": ([_P] * 6 + [_I] * 2 + [_F] * 2 + [_P], _I),
     "simpb_bank_update": ([_P] * 10 + [_I] * 5 + [_P], _I),
-    "simpb_bank_cache": ([_P] * 10 + [_I] * 6 + [_F, _I, _F, _P, _I, _P], _I),
+    "simpb_bank_update_rank": ([_P, _P] + [_I] * 4 + [_P], _I),
+    "simpb_bank_update_merge": ([_P] * 13 + [_I, _P] + [_I] * 5 + [_P], _I),
+    "simpb_bank_cache": ([_P] * 10 + [_I] * 6 + [_F, _I, _F, _P, _I, _P, _P], _I),
     "simpb_decode3d_record": ([_P] * 6 + [_I] * 4 + [_P], _I),
     "simpb_decode2d_record": ([_P] * 6 + [_I] * 4 + [_F] * 4 + [_P], _I),
     "simpb_topk_rows": ([_P, _P, _P, _I, _I, _I, _P], _I),

@@ -105,42 +105,62 @@ __global__ __launch_bounds__(512) void bank_update_rank_kernel(int* __restrict__
   for (int r = tid; r < fresh; r += 512) index[(size_t)b * fresh + r] = (int)key_index(key[r]);
 }
 
+// A frame whose 2D query set overflowed its static capacity is re-run by the caller with a larger one
+// (simpb_amd/runner.py); `hold` are that frame's overflow flags (simpb_alloc_group_start): when any is set the
+// frame-end commit below leaves the persistent state exactly as the frame found it. `sticky` (device word, may be NULL)
+// chains the hold across frames that are decoded before the host has seen the previous frame's flags: the commit of a
+// frame writes "I held back" into it, and the next frame's update / commit treat a set word like a flag of their own
+// (that next frame computed on a state that is going to be rolled back, so it is re-run as well: runner.py).
+__device__ __forceinline__ bool held(const int* hold, int num_hold, const int* sticky = nullptr) {
+  bool h = sticky && *sticky != 0;
+  for (int k = 0; k < num_hold; ++k) h |= hold[k] != 0;
+  return h;
+}
+
 // ---- update (:140-149): rows [0, T) = cached, rows [T, A) = current[index], per stream under its mask; one
-// wave per output row (feature C floats + anchor 11 floats); the ids of masked-out streams are reset (:147-149)
+// wave per output row (feature C floats + anchor 11 floats [+ embedding E floats]); the ids of masked-out streams are reset
+// (:147-149) -- unless a `hold` flag is set: then this frame (or the one decoded just before it) is going to be re-run from
+// the state it found, and that state includes the ids.
+// Embeddings (optional): the anchor embedding is a row-wise function of the anchor (SparseBox3DEncoder), so the embedding
+// of the merged set is the same merge of the embeddings of its two sources -- cached_e = encoder(cached anchors as warped
+// by bank_get), cur_e = encoder(current anchors) -- and the encoder launch behind the update (simpb_head.py:621-622) is a
+// row gather here.
 __global__ __launch_bounds__(64) void bank_merge_kernel(float* __restrict__ out_f, float* __restrict__ out_a,
                                                         long long* __restrict__ instance_id,
                                                         const float* __restrict__ cur_f, const float* __restrict__ cur_a,
                                                         const float* __restrict__ cached_f, const float* __restrict__ cached_a,
                                                         const int* __restrict__ index, const unsigned char* __restrict__ mask,
-                                                        int A, int T, int C) {
+                                                        int A, int T, int C, float* __restrict__ out_e,
+                                                        const float* __restrict__ cur_e, const float* __restrict__ cached_e, int E,
+                                                        const int* __restrict__ hold, int num_hold,
+                                                        const int* __restrict__ sticky) {
   const int r = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const bool use = mask[b] != 0;
   const float* sf;
   const float* sa;
+  const float* se = nullptr;
   if (!use) {
     sf = cur_f + ((size_t)b * A + r) * C;
     sa = cur_a + ((size_t)b * A + r) * 11;
+    if (out_e) se = cur_e + ((size_t)b * A + r) * E;
   } else if (r < T) {
     sf = cached_f + ((size_t)b * T + r) * C;
     sa = cached_a + ((size_t)b * T + r) * 11;
+    if (out_e) se = cached_e + ((size_t)b * T + r) * E;
   } else {
     const int src = index[(size_t)b * (A - T) + (r - T)];
     sf = cur_f + ((size_t)b * A + src) * C;
     sa = cur_a + ((size_t)b * A + src) * 11;
+    if (out_e) se = cur_e + ((size_t)b * A + src) * E;
   }
   float* of = out_f + ((size_t)b * A + r) * C;
   for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(of + c) = *reinterpret_cast<const float4*>(sf + c);
+  if (out_e) {
+    float* oe = out_e + ((size_t)b * A + r) * E;
+    for (int c = lane * 4; c < E; c += 256) *reinterpret_cast<float4*>(oe + c) = *reinterpret_cast<const float4*>(se + c);
+  }
   if (lane < 11) out_a[((size_t)b * A + r) * 11 + lane] = sa[lane];
-  if (!use && instance_id && lane == 0) instance_id[(size_t)b * A + r] = -1;
-}
-
-// A frame whose 2D query set overflowed its static capacity is re-run by the caller with a larger one
-// (simpb_amd/runner.py); `hold` are that frame's overflow flags (simpb_alloc_group_start): when any is set the
-// frame-end commit below leaves the persistent state exactly as the frame found it.
-__device__ __forceinline__ bool held(const int* hold, int num_hold) {
-  bool h = false;
-  for (int k = 0; k < num_hold; ++k) h |= hold[k] != 0;
-  return h;
+  if (!use && instance_id && lane == 0 && !held(hold, num_hold, sticky)) instance_id[(size_t)b * A + r] = -1;
 }
 
 // ---- cache (:152-167) + get_instance_id (:169-184) + update_instance_id (:186-196): ONE workgroup walks the
@@ -150,13 +170,18 @@ __global__ __launch_bounds__(512) void bank_cache_kernel(float* __restrict__ con
                                                          long long* __restrict__ prev_id, const float* __restrict__ cls,
                                                          int bs, int A, int C, int T, int has_prev, float decay,
                                                          int has_threshold, float threshold, const int* __restrict__ hold,
-                                                         int num_hold) {
+                                                         int num_hold, int* __restrict__ sticky) {
   __shared__ unsigned long long key[kCap];
   __shared__ long long ids[kCap];
   __shared__ int scan[kCap];
   __shared__ float fresh_score[kCap];
   const int tid = threadIdx.x;
-  if (held(hold, num_hold)) return;  // wave-uniform: the frame is re-run by the caller, the state stays as it was
+  const bool hold_back = held(hold, num_hold, sticky);
+  if (sticky) {   // what the frame decoded after this one has to respect (every thread has read the word before it changes)
+    __syncthreads();
+    if (tid == 0) *sticky = hold_back ? 1 : 0;
+  }
+  if (hold_back) return;  // workgroup-uniform: the frame is re-run by the caller, the state stays as it was
   long long next_id = *prev_id;
   for (int b = 0; b < bs; ++b) {
     // scores: sigmoid of the best class; tracked instances keep max(decayed previous, new) (:157-162)
@@ -218,9 +243,10 @@ __global__ __launch_bounds__(512) void bank_cache_kernel(float* __restrict__ con
 __global__ __launch_bounds__(64) void bank_gather_kernel(float* __restrict__ out_f, float* __restrict__ out_a,
                                                          const float* __restrict__ src_f, const float* __restrict__ src_a,
                                                          const int* __restrict__ index, int A, int T, int C,
-                                                         const int* __restrict__ hold, int num_hold) {
+                                                         const int* __restrict__ hold, int num_hold,
+                                                         const int* __restrict__ sticky) {
   const int r = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  if (held(hold, num_hold)) return;
+  if (held(hold, num_hold, sticky)) return;   // (sticky: as bank_cache_kernel left it one launch earlier)
   const int src = index[(size_t)b * T + r];
   const float* sf = src_f + ((size_t)b * A + src) * C;
   float* of = out_f + ((size_t)b * T + r) * C;
@@ -244,28 +270,51 @@ extern "C" int simpb_bank_get(float* anchor_out, unsigned char* mask_out, float*
   return simpb_check_launch();
 }
 
+extern "C" int simpb_bank_update_rank(int* index_scratch, const float* cls, int batch_size, int num_anchors, int num_classes,
+                                      int num_temp, void* stream) {
+  if (!index_scratch || !cls || batch_size <= 0 || num_anchors <= 0 || num_anchors > kCap || num_classes <= 0 || num_temp <= 0 ||
+      num_temp >= num_anchors || batch_size > 65535)
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(bank_update_rank_kernel, dim3(batch_size), dim3(512), 0, static_cast<hipStream_t>(stream), index_scratch, cls,
+                     num_anchors, num_classes, num_anchors - num_temp);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_bank_update_merge(float* feature_out, float* anchor_out, float* embed_out, long long* instance_id,
+                                       const int* index, const float* feature, const float* anchor, const float* embed,
+                                       const float* cached_feature, const float* cached_anchor, const float* cached_embed,
+                                       const unsigned char* mask, const int* hold, int num_hold, const int* sticky,
+                                       int batch_size, int num_anchors, int num_temp, int embed_dims, int pos_embed_dims,
+                                       void* stream) {
+  if (!feature_out || !anchor_out || !index || !feature || !anchor || !cached_feature || !cached_anchor || !mask ||
+      batch_size <= 0 || num_anchors <= 0 || num_anchors > kCap || num_temp <= 0 || num_temp >= num_anchors || embed_dims <= 0 ||
+      (embed_dims & 3) || batch_size > 65535 || num_hold < 0 || (num_hold > 0 && !hold))
+    return SIMPB_EINVAL;
+  if (embed_out && (!embed || !cached_embed || pos_embed_dims <= 0 || (pos_embed_dims & 3))) return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(bank_merge_kernel, dim3(num_anchors, batch_size), dim3(64), 0, static_cast<hipStream_t>(stream), feature_out,
+                     anchor_out, instance_id, feature, anchor, cached_feature, cached_anchor, index, mask, num_anchors, num_temp,
+                     embed_dims, embed_out, embed, cached_embed, pos_embed_dims, hold, num_hold, sticky);
+  return simpb_check_launch();
+}
+
 extern "C" int simpb_bank_update(float* feature_out, float* anchor_out, long long* instance_id, int* index_scratch,
                                  const float* feature, const float* anchor, const float* cls, const float* cached_feature,
                                  const float* cached_anchor, const unsigned char* mask, int batch_size, int num_anchors,
                                  int num_classes, int num_temp, int embed_dims, void* stream) {
-  if (!feature_out || !anchor_out || !index_scratch || !feature || !anchor || !cls || !cached_feature || !cached_anchor ||
-      !mask || batch_size <= 0 || num_anchors <= 0 || num_anchors > kCap || num_classes <= 0 || num_temp <= 0 ||
-      num_temp >= num_anchors || embed_dims <= 0 || (embed_dims & 3) || batch_size > 65535)
-    return SIMPB_EINVAL;
-  (void)hipGetLastError();
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(bank_update_rank_kernel, dim3(batch_size), dim3(512), 0, s, index_scratch, cls, num_anchors, num_classes,
-                     num_anchors - num_temp);
-  hipLaunchKernelGGL(bank_merge_kernel, dim3(num_anchors, batch_size), dim3(64), 0, s, feature_out, anchor_out, instance_id,
-                     feature, anchor, cached_feature, cached_anchor, index_scratch, mask, num_anchors, num_temp, embed_dims);
-  return simpb_check_launch();
+  const int st = simpb_bank_update_rank(index_scratch, cls, batch_size, num_anchors, num_classes, num_temp, stream);
+  if (st != SIMPB_OK) return st;
+  return simpb_bank_update_merge(feature_out, anchor_out, nullptr, instance_id, index_scratch, feature, anchor, nullptr,
+                                 cached_feature, cached_anchor, nullptr, mask, nullptr, 0, nullptr, batch_size, num_anchors,
+                                 num_temp, embed_dims, 0, stream);
 }
 
 extern "C" int simpb_bank_cache(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
                                 long long* prev_id, long long* ids_out, int* index_scratch, const float* feature,
                                 const float* anchor, const float* cls, int batch_size, int num_anchors, int num_classes,
                                 int num_temp, int embed_dims, int has_previous, float confidence_decay, int has_threshold,
-                                float threshold, const int* hold, int num_hold, void* stream) {
+                                float threshold, const int* hold, int num_hold, int* sticky, void* stream) {
   if (!confidence || !cached_feature || !cached_anchor || !prev_id || !ids_out || !index_scratch || !feature || !anchor ||
       !cls || batch_size <= 0 || num_anchors <= 0 || num_anchors > kCap || num_classes <= 0 || num_temp <= 0 ||
       num_temp > num_anchors || embed_dims <= 0 || (embed_dims & 3) || batch_size > 65535 || num_hold < 0 ||
@@ -275,8 +324,8 @@ extern "C" int simpb_bank_cache(float* confidence, float* cached_feature, float*
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bank_cache_kernel, dim3(1), dim3(512), 0, s, confidence, index_scratch, ids_out, instance_id, prev_id, cls,
                      batch_size, num_anchors, num_classes, num_temp, has_previous, confidence_decay, has_threshold, threshold, hold,
-                     num_hold);
+                     num_hold, sticky);
   hipLaunchKernelGGL(bank_gather_kernel, dim3(num_temp, batch_size), dim3(64), 0, s, cached_feature, cached_anchor, feature,
-                     anchor, index_scratch, num_anchors, num_temp, embed_dims, hold, num_hold);
+                     anchor, index_scratch, num_anchors, num_temp, embed_dims, hold, num_hold, sticky);
   return simpb_check_launch();
 }

@@ -281,15 +281,16 @@ class SimPBHead(BaseModule):
         last = len(self.operation_order) - 1
         # static mode: the overflow flags of the frame's allocation layers in one tensor; the frame-end commit of the
         # bank holds back when any is set, so that the caller can re-run the frame (runner.py) on untouched state
-        overflow = hold = None
+        overflow = hold = sticky = None
         if cap is not None:
             n_alloc = sum(op == "allocation" for op in self.operation_order)
             chain = metas.get("overflow_chain")
             sticky = None
             if split:
-                # (hb i32 [n_alloc + 1] owned by the caller, sticky i32 [1]): this frame's flags live in hb[:n_alloc]; the
-                # last entry receives, when the temporal part starts, the `sticky` word the frame decoded before this one
-                # left (1 = that frame held its commit back), and this frame leaves max(hb) in `sticky` in turn
+                # (hb i32 [n_alloc + 1] owned by the caller, sticky i32 [1]): this frame's flags live in hb[:n_alloc] (the
+                # last entry is spare); `sticky` is the word the frame decoded before this one left (1 = it held its commit
+                # back): the bank kernels of the temporal part treat it like a flag of this frame, and this frame's commit
+                # leaves its own verdict in it in turn (csrc/bank.hip)
                 hb, sticky = metas["overflow_split"]
                 if hb.dtype != torch.int32 or hb.numel() != n_alloc + 1 or sticky.dtype != torch.int32 or sticky.numel() != 1:
                     raise ValueError("overflow_split: (i32 [allocation layers + 1], i32 [1])")
@@ -383,16 +384,32 @@ class SimPBHead(BaseModule):
                 prediction.append(anchor)
                 classification.append(cls)
                 quality.append(qt)
+                merged_embed = None
                 if len(prediction) == self.num_single_frame_decoder:
+                    # what InstanceBank.update needs from THIS frame does not depend on the bank: the ranking of the current
+                    # instances (by this layer's classification) and the embedding of their refined anchors. Both are taken
+                    # here, in front of the point where a caller overlapping frames starts to wait for the previous frame; the
+                    # update then merges embeddings along with features and anchors (rows follow their anchors), and the
+                    # encoder launch behind it (:621-622) is not needed.
+                    rank = cur_embed = None
+                    if anchor.is_cuda and routes.R.dense and i != last:
+                        rank = self.instance_bank.rank_current(instance_feature, cls)
+                        if rank is not None:
+                            cur_embed = self.anchor_encoder.forward(anchor)   # (no call site of the reference: no hooks)
                     if split:
                         yield "single-frame layers done"
                         # ---- the temporal part: needs what the previous frame's decoder committed
                         _, _, temp_instance_feature, temp_anchor, time_interval = self.instance_bank.get(
                             batch_size, metas, dn_metas=None)
                         temp_anchor_embed = self.anchor_encoder(temp_anchor) if temp_anchor is not None else None
-                        hold[-1:].copy_(sticky)
-                    instance_feature, anchor = self.instance_bank.update(instance_feature, anchor, cls)
-                if i != last:
+                    if rank is not None:
+                        instance_feature, anchor, merged_embed = self.instance_bank.update(
+                            instance_feature, anchor, cls, rank=rank, embed=(cur_embed, temp_anchor_embed), hold=hold, sticky=sticky)
+                    else:
+                        instance_feature, anchor = self.instance_bank.update(instance_feature, anchor, cls)
+                if merged_embed is not None:
+                    anchor_embed = dense.report(self.anchor_encoder, merged_embed)
+                elif i != last:
                     anchor_embed = self.anchor_encoder(anchor)
                 if len(prediction) > self.num_single_frame_decoder and temp_anchor_embed is not None:
                     temp_anchor_embed = anchor_embed[:, : self.instance_bank.num_temp_instances]
@@ -408,12 +425,12 @@ class SimPBHead(BaseModule):
             "alloc_list": alloc_list, "overflow": overflow,
         }
         ids = self.instance_bank.cache_and_assign_ids(instance_feature, anchor, cls, metas, self.decoder.score_threshold,
-                                                      hold=hold)
+                                                      hold=hold, sticky=sticky)
         if ids is None:
             self.instance_bank.cache(instance_feature, anchor, cls, metas, feature_maps)
             ids = self.instance_bank.get_instance_id(cls, anchor, self.decoder.score_threshold)
-        if split:
-            torch.amax(hold, dim=0, keepdim=True, out=sticky)   # what the next frame's commit has to respect
+        if split and ids is None:   # (the commit kernel leaves the word itself; this is the route without it)
+            torch.amax(torch.cat([hold, sticky]), dim=0, keepdim=True, out=sticky)   # what the next frame's commit has to respect
         output["instance_id"] = ids
         return output
 

@@ -175,30 +175,55 @@ class InstanceBank(nn.Module):
         return feature, anchor, self.cached_feature, self.cached_anchor, dt
 
     # ------------------------------------------------------------------ after the first decoder layer
-    def update(self, instance_feature, anchor, confidence):
+    def rank_current(self, instance_feature, confidence):
+        """The ranking step of update() (instance_bank.py:137: top (num_anchor - num_temp) current instances by max-class
+        logit): it depends on the first decoder layer's classification only, not on the bank, so callers that overlap frames
+        run it before they wait for the previous frame (SimPBHead.forward_split). None where the fused route does not apply."""
+        if not self._fusable(instance_feature) or instance_feature.shape[1] != self.num_anchor:
+            return None
+        bs, a, _ = instance_feature.shape
+        cls = confidence.contiguous().float()
+        index = torch.empty(bs, a - self.num_temp_instances, dtype=torch.int32, device=cls.device)
+        _lib.check(_lib.lib().simpb_bank_update_rank(_ptr(index), _ptr(cls), bs, a, cls.shape[-1], self.num_temp_instances,
+                                                     _stream()), "simpb_bank_update_rank")
+        return index
+
+    def update(self, instance_feature, anchor, confidence, rank=None, embed=None, hold=None, sticky=None):
         """Replace the 900 current instances by [cached 600 | best 300 current] for streams whose
-        history is valid (instance_bank.py:121-150)."""
+        history is valid (instance_bank.py:121-150). rank: rank_current()'s result, if the caller took it early. embed =
+        (embedding of `anchor`, embedding of the cached anchors get() returned): the merged set's embedding is then
+        returned as a third value (rows follow their anchors), or None where the fused route does not apply."""
         if self.cached_feature is None:
-            return instance_feature, anchor
+            return (instance_feature, anchor) if embed is None else (instance_feature, anchor, embed[0])
         if instance_feature.shape[1] > self.num_anchor:
             raise NotImplementedError("denoising instances only exist in training")
         if (self._fusable(instance_feature) and self.mask is not None and self.mask.dtype == torch.bool
                 and instance_feature.shape[1] == self.num_anchor):
             bs, a, c = instance_feature.shape
             t = self.num_temp_instances
-            out_f = torch.empty(bs, a, c, device=instance_feature.device)
-            out_a = torch.empty(bs, a, anchor.shape[-1], device=instance_feature.device)
-            scratch = torch.empty(bs, a - t, dtype=torch.int32, device=instance_feature.device)
+            dev = instance_feature.device
+            out_f = torch.empty(bs, a, c, device=dev)
+            out_a = torch.empty(bs, a, anchor.shape[-1], device=dev)
+            if rank is None:
+                rank = self.rank_current(instance_feature, confidence)
             ids = self.instance_id if self.instance_id is self._static["instance_id"] else None
-            cls = confidence.contiguous().float()
-            _lib.check(_lib.lib().simpb_bank_update(
-                _ptr(out_f), _ptr(out_a), _ptr(ids) if ids is not None else None, _ptr(scratch),
-                _ptr(instance_feature.contiguous().float()), _ptr(anchor.contiguous().float()), _ptr(cls),
-                _ptr(self.cached_feature.contiguous()), _ptr(self.cached_anchor.contiguous()), _ptr(self.mask), bs, a,
-                cls.shape[-1], t, c, _stream()), "simpb_bank_update")
+            out_e = cur_e = cached_e = None
+            e_dim = 0
+            if embed is not None and embed[1] is not None and embed[1].shape[1] == t and embed[0].shape[-1] % 4 == 0:
+                cur_e, cached_e = embed[0].contiguous().float(), embed[1].contiguous().float()
+                e_dim = cur_e.shape[-1]
+                out_e = torch.empty(bs, a, e_dim, device=dev)
+            _lib.check(_lib.lib().simpb_bank_update_merge(
+                _ptr(out_f), _ptr(out_a), _ptr(out_e) if out_e is not None else None, _ptr(ids) if ids is not None else None,
+                _ptr(rank), _ptr(instance_feature.contiguous().float()), _ptr(anchor.contiguous().float()),
+                _ptr(cur_e) if cur_e is not None else None, _ptr(self.cached_feature.contiguous()),
+                _ptr(self.cached_anchor.contiguous()), _ptr(cached_e) if cached_e is not None else None, _ptr(self.mask),
+                _ptr(hold) if hold is not None else None, 0 if hold is None else hold.numel(),
+                _ptr(sticky) if sticky is not None else None, bs, a, t, c, e_dim, _stream()),
+                "simpb_bank_update_merge")
             if ids is None and self.instance_id is not None:
                 self._keep("instance_id", self.instance_id.masked_fill(~self.mask[:, None], -1))
-            return out_f, out_a
+            return (out_f, out_a) if embed is None else (out_f, out_a, out_e)
         fresh = self.num_anchor - self.num_temp_instances
         _, (best_feature, best_anchor) = topk(confidence.max(dim=-1).values, fresh, instance_feature, anchor)
         merged_feature = torch.cat([self.cached_feature, best_feature], dim=1)
@@ -208,7 +233,7 @@ class InstanceBank(nn.Module):
         anchor = torch.where(keep, merged_anchor, anchor)
         if self.instance_id is not None:
             self._keep("instance_id", self.instance_id.masked_fill(~self.mask[:, None], -1))
-        return instance_feature, anchor
+        return (instance_feature, anchor) if embed is None else (instance_feature, anchor, None)
 
     # ------------------------------------------------------------------ frame end
     def cache(self, instance_feature, anchor, confidence, metas=None, feature_maps=None):
@@ -236,7 +261,7 @@ class InstanceBank(nn.Module):
                 and self.num_anchor <= 1024 and 0 < self.num_temp_instances < self.num_anchor
                 and self.embed_dims % 4 == 0)
 
-    def cache_and_assign_ids(self, instance_feature, anchor, confidence, metas=None, threshold=None, hold=None):
+    def cache_and_assign_ids(self, instance_feature, anchor, confidence, metas=None, threshold=None, hold=None, sticky=None):
         """cache() followed by get_instance_id() (simpb_head.py:744-747) on the persistent state, as two
         launches (csrc/bank.hip). Returns the instance ids, or None when the fused route does not apply
         (the caller then runs the two methods). `hold` (i32 flags on the device): when any is set the launches write
@@ -255,7 +280,8 @@ class InstanceBank(nn.Module):
             _ptr(st["prev_id"]), _ptr(ids_out), _ptr(scratch), _ptr(instance_feature.detach().contiguous().float()),
             _ptr(anchor.detach().contiguous().float()), _ptr(cls), bs, a, cls.shape[-1], t, c, 1 if has_prev else 0,
             float(self.confidence_decay), 0 if threshold is None else 1, 0.0 if threshold is None else float(threshold),
-            _ptr(hold) if hold is not None else None, 0 if hold is None else hold.numel(), _stream()), "simpb_bank_cache")
+            _ptr(hold) if hold is not None else None, 0 if hold is None else hold.numel(),
+            _ptr(sticky) if sticky is not None else None, _stream()), "simpb_bank_cache")
         self.metas = metas
         self.confidence, self.cached_feature, self.cached_anchor = st["confidence"], st["cached_feature"], st["cached_anchor"]
         self.instance_id, self.prev_id = st["instance_id"], st["prev_id"]
