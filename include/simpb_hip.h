@@ -306,6 +306,10 @@ int simpb_attention_f32(float* out, const float* q, const float* k, const float*
  *                            addend x2 (row stride ldx2): input = x + x2
  *                 IN_SINE2D  x f32 rows holding (x, y) in [0,1] at columns 0,1; the 256-d sine embedding
  *                            of models/utils.py:40-63 (cat(pos_y, pos_x)) is computed in the kernel
+ *                 IN_ROWS_LN input = LayerNorm(x) * ln_w + ln_b (eps 1e-5) + x2: the decoder's `norm` operator in front of
+ *                            a refinement head (models/simpb_head.py operation_order "norm", "refine*") inside the head's
+ *                            launch; ln_out (row stride ld_ln_out, may be NULL) receives LayerNorm(x), the operator's
+ *                            own output (rows >= *m_live as zeros). 4-row kernel (weights_transposed == 2) only.
  *   chain output: out rows of the last width, row stride ldo; out_scale (or NULL) multiplies column-wise
  *                 (mmcv Scale after the last Linear); then the optional `post` stage on v = out[row, t]:
  *     POST_REFINE3D  SparseBox3DRefinementModule.forward (models/detection3d/blocks.py:133-143):
@@ -324,6 +328,7 @@ int simpb_attention_f32(float* out, const float* q, const float* k, const float*
 #define SIMPB_MLP_LAYERNORM 1
 #define SIMPB_MLP_IN_ROWS 0
 #define SIMPB_MLP_IN_SINE2D 1
+#define SIMPB_MLP_IN_ROWS_LN 2
 typedef struct simpb_mlp_op {
   int type, in_dim, out_dim, relu;
   const float* w;
@@ -339,6 +344,10 @@ typedef struct simpb_mlp_chain {
   const float* res;
   const float* div;
   simpb_mlp_op ops[SIMPB_MLP_MAX_OPS];
+  const float* ln_w;   /* IN_ROWS_LN: gamma, beta f32 [in_dim] */
+  const float* ln_b;
+  float* ln_out;
+  int ld_ln_out, reserved2;
 } simpb_mlp_chain;
 typedef struct simpb_mlp_args {
   int num_rows, num_chains;

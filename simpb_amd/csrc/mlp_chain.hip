@@ -66,6 +66,11 @@ __device__ __forceinline__ bool skip_dead_rows(const simpb_mlp_args& args, const
     const int r = idx / width, t = idx - r * width;
     if (row0 + r < args.num_rows) ch.out[(size_t)(row0 + r) * ch.ldo + t] = 0.f;
   }
+  if (ch.in_mode == SIMPB_MLP_IN_ROWS_LN && ch.ln_out)
+    for (int idx = tid; idx < rows * ch.in_dim; idx += nthreads) {
+      const int r = idx / ch.in_dim, t = idx - r * ch.in_dim;
+      if (row0 + r < args.num_rows) ch.ln_out[(size_t)(row0 + r) * ch.ld_ln_out + t] = 0.f;
+    }
   return true;
 }
 
@@ -539,6 +544,43 @@ __global__ __launch_bounds__(256) void mlp_chain_r4_kernel(simpb_mlp_args args) 
       }
       act[0][r][j] = v;
     }
+  } else if (ch.in_mode == SIMPB_MLP_IN_ROWS_LN) {
+    // the decoder's `norm` operator in front of this head, inside the launch: wave r = row r, 64 lanes x 4 elements (the
+    // LayerNorm stage's arithmetic below), + x2 afterwards; the chain that carries ln_out writes the operator's output
+    const int D = ch.in_dim, r = wave, row = row0 + r;
+    const int live = args.m_live ? min(N, *args.m_live) : N;
+    const bool in_rows = row < N, alive = row < live;
+    float g[kMaxDim / 64], be[kMaxDim / 64], v[kMaxDim / 64], x2v[kMaxDim / 64];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxDim / 64; ++j) {
+      const int e = lane + 64 * j;
+      const bool in = e < D;
+      g[j] = in ? ch.ln_w[e] : 0.f;
+      be[j] = in ? ch.ln_b[e] : 0.f;
+      v[j] = (in && in_rows) ? ch.x[(size_t)row * ch.ldx + e] : 0.f;
+      x2v[j] = (in && in_rows && ch.x2) ? ch.x2[(size_t)row * ch.ldx2 + e] : 0.f;
+      sum += v[j];
+    }
+    sum = wave_sum(sum);
+    const float mean = sum / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxDim / 64; ++j) {
+      const float d = (lane + 64 * j) < D ? v[j] - mean : 0.f;
+      q += d * d;
+    }
+    q = wave_sum(q);
+    const float inv = 1.f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < kMaxDim / 64; ++j) {
+      const int e = lane + 64 * j;
+      if (e < D) {
+        const float y = alive ? (v[j] - mean) * inv * g[j] + be[j] : 0.f;   // (capacity rows: zeros, as the LayerNorm launch wrote)
+        if (ch.ln_out && in_rows) ch.ln_out[(size_t)row * ch.ld_ln_out + e] = y;
+        act[0][r][e] = y + x2v[j];
+      }
+    }
   } else {
     for (int idx = tid; idx < kR4 * ch.in_dim; idx += kThreads) {
       const int r = idx / ch.in_dim, k = idx - r * ch.in_dim;
@@ -680,6 +722,10 @@ extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream)
       return SIMPB_EINVAL;
     if (ch.post == SIMPB_MLP_POST_REFINE3D && ch.div && ch.div_rows <= 0) return SIMPB_EINVAL;
     if (ch.in_mode == SIMPB_MLP_IN_SINE2D && ch.ldx < 2) return SIMPB_EINVAL;
+    if (ch.in_mode == SIMPB_MLP_IN_ROWS_LN && (args->weights_transposed != 2 || !ch.ln_w || !ch.ln_b ||
+                                               (ch.ln_out && ch.ld_ln_out < ch.in_dim)))
+      return SIMPB_EINVAL;
+    if (ch.in_mode < 0 || ch.in_mode > SIMPB_MLP_IN_ROWS_LN) return SIMPB_EINVAL;
     for (int o = 0; o < ch.n_ops; ++o) {
       const simpb_mlp_op& op = ch.ops[o];
       if (op.type == SIMPB_MLP_LINEAR) {

@@ -5,6 +5,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import routes
 from .layers import BaseModule, Linear, Scale, bias_init_with_prob, linear_relu_ln
 from .registry import PLUGIN_LAYERS, POSITIONAL_ENCODING
 
@@ -104,8 +105,15 @@ class SparseBox2DRefinementModule(BaseModule):
         if self.with_cls_branch:
             nn.init.constant_(self.cls_layers[-1].bias, bias_init_with_prob(0.01))
 
-    def forward(self, instance_feature, anchor2d, anchor2d_embed, metas=None, return_cls=True, query_groups=None, m_live=None):
+    def forward(self, instance_feature, anchor2d, anchor2d_embed, metas=None, return_cls=True, query_groups=None, m_live=None,
+                norm=None):
+        """norm: as SparseBox3DRefinementModule.forward (the `norm` operator in front of this head, not applied yet)."""
         fused_ok = instance_feature.is_cuda
+        self.norm_out = None
+        if norm is not None and not (fused_ok and routes.R.chain_rows4):
+            from . import dense
+            instance_feature = self.norm_out = dense.layernorm(instance_feature, norm, m_live=m_live)
+            norm = None
         if fused_ok:
             from . import fused
             xf, ldx = fused._rows(instance_feature, instance_feature.shape[-1])
@@ -115,16 +123,21 @@ class SparseBox2DRefinementModule(BaseModule):
             # :122-125 + the final sigmoid (:144) as the chain's post stage
             af, lda = fused._rows(anchor2d, anchor2d.shape[-1])
             post = dict(kind=fused.POST_REFINE2D, res=(af, lda), res_cols=anchor2d.shape[-1])
+            ln_w = ln_r = None
+            if norm is not None:   # every chain normalises its rows itself; the first one writes the operator's output
+                normed = torch.empty(n, xf.shape[1], device=xf.device)
+                self.norm_out = normed.reshape(instance_feature.shape)
+                ln_w, ln_r = (norm, (normed, xf.shape[1])), (norm, None)
             jobs = [dict(plan=fused.plan_of(self.layers), x=(xf, ldx, 0), x2=(ef, lde, 0), out=(out_t, self.output_dim, 0),
-                         post=post)]
+                         post=post, ln=ln_w)]
             cls_t = alpha_t = None
             if return_cls:
                 cls_t = torch.empty(n, self.num_cls, device=xf.device)
-                jobs.append(dict(plan=fused.plan_of(self.cls_layers), x=(xf, ldx, 0), out=(cls_t, self.num_cls, 0)))
+                jobs.append(dict(plan=fused.plan_of(self.cls_layers), x=(xf, ldx, 0), out=(cls_t, self.num_cls, 0), ln=ln_r))
             if self.with_alpha_branch:
                 adim = fused.plan_of(self.alpha_layers).out_dim
                 alpha_t = torch.empty(n, adim, device=xf.device)
-                jobs.append(dict(plan=fused.plan_of(self.alpha_layers), x=(xf, ldx, 0), out=(alpha_t, adim, 0)))
+                jobs.append(dict(plan=fused.plan_of(self.alpha_layers), x=(xf, ldx, 0), out=(alpha_t, adim, 0), ln=ln_r))
             if n:
                 fused.run_chains(jobs, n, xf.device, m_live=m_live)
             output = out_t.reshape(lead + (self.output_dim,))

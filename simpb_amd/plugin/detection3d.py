@@ -108,9 +108,18 @@ class SparseBox3DRefinementModule(BaseModule):
         if self.with_cls_branch:
             nn.init.constant_(self.cls_layers[-1].bias, bias_init_with_prob(0.01))
 
-    def forward(self, instance_feature, anchor, anchor_embed, time_interval=1.0, return_cls=True):
+    def forward(self, instance_feature, anchor, anchor_embed, time_interval=1.0, return_cls=True, norm=None):
+        """norm (an nn.LayerNorm, or None): the decoder's `norm` operator in front of this head has NOT been applied to
+        instance_feature yet; the head's chain launch applies it (and leaves its output in self.norm_out), or, on the
+        routes without that stage, it is applied here first."""
         fused_ok = instance_feature.is_cuda
-        if fused_ok and not self.normalize_yaw and self.output_dim == 11 and anchor.shape[-1] == 11 and self.refine_yaw:
+        one_launch = fused_ok and not self.normalize_yaw and self.output_dim == 11 and anchor.shape[-1] == 11 and self.refine_yaw
+        self.norm_out = None
+        if norm is not None and not (one_launch and routes.R.chain_rows4):
+            from . import dense
+            instance_feature = self.norm_out = dense.layernorm(instance_feature, norm)
+            norm = None
+        if one_launch:
             # the whole head in one launch: MLP, Scale, then :133-143 (anchor added on every state, the
             # velocity columns divided by the time step first) as the chain's post stage
             from . import fused
@@ -126,17 +135,22 @@ class SparseBox3DRefinementModule(BaseModule):
             ef, lde = fused._rows(anchor_embed, anchor_embed.shape[-1])
             n, lead = xf.shape[0], instance_feature.shape[:-1]
             out = torch.empty(n, self.output_dim, device=xf.device)
+            ln_w = ln_r = None
+            if norm is not None:   # every chain normalises its rows itself; the first one writes the operator's output
+                normed = torch.empty(n, xf.shape[1], device=xf.device)
+                self.norm_out = normed.reshape(instance_feature.shape)
+                ln_w, ln_r = (norm, (normed, xf.shape[1])), (norm, None)
             jobs = [dict(plan=fused.plan_of(self.layers), x=(xf, ldx, 0), x2=(ef, lde, 0), out=(out, self.output_dim, 0),
-                         post=post)]
+                         post=post, ln=ln_w)]
             cls = quality = None
             if return_cls:
                 assert self.with_cls_branch, "Without classification layers !!!"
                 cls = torch.empty(n, self.num_cls, device=xf.device)  # cls_layers(feature), :145-147
-                jobs.append(dict(plan=fused.plan_of(self.cls_layers), x=(xf, ldx, 0), out=(cls, self.num_cls, 0)))
+                jobs.append(dict(plan=fused.plan_of(self.cls_layers), x=(xf, ldx, 0), out=(cls, self.num_cls, 0), ln=ln_r))
                 if self.with_quality_estimation:  # quality_layers(feature + embed), :149-152
                     quality = torch.empty(n, 2, device=xf.device)
                     jobs.append(dict(plan=fused.plan_of(self.quality_layers), x=(xf, ldx, 0), x2=(ef, lde, 0),
-                                     out=(quality, 2, 0)))
+                                     out=(quality, 2, 0), ln=ln_r))
                     quality = quality.reshape(lead + (2,))
                 cls = cls.reshape(lead + (self.num_cls,))
             if n:

@@ -18,7 +18,7 @@ POST_NONE, POST_REFINE3D, POST_REFINE2D, POST_SIGMOID = 0, 1, 2, 3
 # (csrc/mlp_chain.hip: mlp_chain_r4_kernel): 225 workgroups for 900 rows instead of 57. Off: the 16-row matrix-core kernel
 # on the weights as stored, or (routes.chain_transposed) the VALU kernel on transposed copies.
 LINEAR, LAYERNORM = 0, 1
-IN_ROWS, IN_SINE2D = 0, 1
+IN_ROWS, IN_SINE2D, IN_ROWS_LN = 0, 1, 2
 
 
 class _Op(ctypes.Structure):
@@ -32,7 +32,8 @@ class _Chain(ctypes.Structure):
                 ("in_dim", ctypes.c_int), ("in_mode", ctypes.c_int), ("n_ops", ctypes.c_int),
                 ("post", ctypes.c_int), ("ldres", ctypes.c_int), ("res_cols", ctypes.c_int), ("div_rows", ctypes.c_int),
                 ("div_col0", ctypes.c_int), ("reserved", ctypes.c_int), ("res", ctypes.c_void_p), ("div", ctypes.c_void_p),
-                ("ops", _Op * MAX_OPS)]
+                ("ops", _Op * MAX_OPS), ("ln_w", ctypes.c_void_p), ("ln_b", ctypes.c_void_p), ("ln_out", ctypes.c_void_p),
+                ("ld_ln_out", ctypes.c_int), ("reserved2", ctypes.c_int)]
 
 
 class _Args(ctypes.Structure):
@@ -142,7 +143,8 @@ def _rows(t, width):
 
 def run_chains(jobs, num_rows, device, m_live=None):
     """jobs: list of dicts(plan, x=(tensor2d, ld, col), x2=(tensor2d, ld, col) or None, out=(tensor2d, ld, col),
-    sine=bool, post=dict(kind, res=(tensor2d, ld), res_cols, div=tensor or None, div_rows, div_col0) or None).
+    sine=bool, post=dict(kind, res=(tensor2d, ld), res_cols, div=tensor or None, div_rows, div_col0) or None,
+    ln=(nn.LayerNorm over x, (out tensor2d, ld) or None) or None: input = LayerNorm(x) + x2, LayerNorm(x) written to out).
     All tensors f32 on `device`, 2-D views with unit inner stride. m_live: device i32 [1] or None; rows past it are capacity
     slots of the static 2D query set and come out as zeros (their workgroups do no work)."""
     if not jobs or len(jobs) > MAX_CHAINS:
@@ -167,6 +169,15 @@ def run_chains(jobs, num_rows, device, m_live=None):
         ch.out, ch.ldo = ot.data_ptr() + 4 * ocol, ldo
         ch.in_mode = IN_SINE2D if job.get("sine") else IN_ROWS
         ch.in_dim = plan.in_dim
+        if job.get("ln") is not None:
+            ln, ln_out = job["ln"]
+            if not routes.R.chain_rows4 or ln.normalized_shape != (plan.in_dim,) or abs(ln.eps - 1e-5) > 1e-12 or job.get("sine"):
+                raise ValueError("a leading LayerNorm needs the 4-row chain kernel and a norm of the chain's input width")
+            ch.in_mode = IN_ROWS_LN
+            ch.ln_w, ch.ln_b = ln.weight.data_ptr(), ln.bias.data_ptr()
+            if ln_out is not None:
+                ch.ln_out, ch.ld_ln_out = ln_out[0].data_ptr(), ln_out[1]
+                keep.append(ln_out[0])
         post = job.get("post")
         if post:
             ch.post = post["kind"]

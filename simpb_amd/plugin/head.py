@@ -281,6 +281,7 @@ class SimPBHead(BaseModule):
         last = len(self.operation_order) - 1
         # static mode: the overflow flags of the frame's allocation layers in one tensor; the frame-end commit of the
         # bank holds back when any is set, so that the caller can re-run the frame (runner.py) on untouched state
+        pending_norm = None
         overflow = hold = sticky = None
         if cap is not None:
             n_alloc = sum(op == "allocation" for op in self.operation_order)
@@ -315,7 +316,12 @@ class SimPBHead(BaseModule):
             if layer is None:
                 continue
             elif op == "norm":
-                if instance_feature.is_cuda and routes.R.dense:
+                nxt = self.operation_order[i + 1] if i < last else None
+                if (instance_feature.is_cuda and routes.R.dense and routes.R.norm_in_refine and routes.R.chain_rows4
+                        and nxt in ("refine2d", "refine3d") and self.layers[i + 1] is not None
+                        and torch.is_tensor(instance_feature) and abs(layer.eps - 1e-5) < 1e-12):
+                    pending_norm = layer   # applied inside the refinement head's launch, which writes this operator's output
+                elif instance_feature.is_cuda and routes.R.dense:
                     instance_feature = dense.layernorm(instance_feature, layer, m_live=self._m_live)
                 else:
                     instance_feature = layer(instance_feature)
@@ -357,8 +363,12 @@ class SimPBHead(BaseModule):
                                          keep_parts=routes.R.dense and self._next_is_ffn(i), **enc)
             elif op == "refine2d":
                 kw = dict(m_live=self._m_live) if self._m_live is not None else {}
+                if pending_norm is not None:
+                    kw["norm"] = pending_norm
                 anchor2d, cls2d, depth2d, alpha2d = layer(instance_feature, anchor2d, anchor_embed2d, metas=metas,
                                                           query_groups=ref_query_groups, **kw)
+                if pending_norm is not None:
+                    instance_feature, pending_norm = dense.report(pending_norm, layer.norm_out), None
                 prediction2d.append(anchor2d)
                 classification2d.append(cls2d)
                 prediction_alpha2d.append(alpha2d)
@@ -378,9 +388,12 @@ class SimPBHead(BaseModule):
                                          keep_parts=routes.R.dense and self._next_is_ffn(i),
                                          cam_embed=cam_embeds.get(i))
             elif op == "refine3d":
+                kw = dict(norm=pending_norm) if pending_norm is not None else {}
                 anchor, cls, qt = layer(
                     instance_feature, anchor, anchor_embed, time_interval=time_interval,
-                    return_cls=(len(prediction) == self.num_single_frame_decoder - 1 or i == last))
+                    return_cls=(len(prediction) == self.num_single_frame_decoder - 1 or i == last), **kw)
+                if pending_norm is not None:
+                    instance_feature, pending_norm = dense.report(pending_norm, layer.norm_out), None
                 prediction.append(anchor)
                 classification.append(cls)
                 quality.append(qt)

@@ -45,6 +45,9 @@ DEFAULTS = dict(
     # (query, head), project the 8 x 256 sums with the folded W_out . W_value afterwards (csrc/msda_lin.hip; linearity).
     # False: value_proj over every token (with the backbone, runner.precompute_values) + the sampler on its output.
     msda_linear=True,
+    # the `norm` operator in front of a refinement head runs inside the head's chain launch (leading LayerNorm stage of
+    # csrc/mlp_chain.hip's 4-row kernel, which also writes the operator's output). False: a LayerNorm launch of its own.
+    norm_in_refine=True,
     # DeformableFeatureAggregation: key points + projection + weight softmax inside the aggregation launch
     # (csrc/deform_agg_fused.hip). False: dfa_points + dfa_weights + the drop-in aggregation operator (three launches).
     fused_dfa=True,

@@ -251,7 +251,8 @@ def test_dfa_fused_launch_equals_three_launches(f16):
         with torch.no_grad():
             with routes.override(fused_dfa=False):
                 want = dfa(feat, anchor, emb, fm, m)
-            got = dfa(feat, anchor, emb, fm, m)
+            with routes.override(dfa_f16_tokens=f16):   # (shipped: the fp32 rows; the f16 copy is the measured alternative)
+                got = dfa(feat, anchor, emb, fm, m)
     finally:
         blocks.DAF, blocks.dfa_fused = orig, orig_fused
     assert seen["fdtype"] == (torch.float16 if f16 else torch.float32)
@@ -443,3 +444,47 @@ def test_aggregate_with_alpha_in_launch_equals_two_launches():
             if len(s):
                 ref[b, a] += (al[b, s, None] * q2d[b, s].double()).sum(0) / al[b, s].sum().clamp(min=1e-5)
     assert float((got[0].cpu().double() - ref).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("live", [None, 301])
+def test_norm_inside_the_refinement_launch_equals_norm_then_head(live):
+    """The decoder's `norm` operator applied by the refinement head's own chain launch (leading LayerNorm stage of the 4-row
+    chain kernel, csrc/mlp_chain.hip) against the LayerNorm launch followed by the head: same box / class / quality (alpha)
+    outputs and the same operator output, 3D and 2D heads, with and without capacity rows."""
+    from simpb_amd.plugin import dense
+    from simpb_amd.plugin.detection2d import SparseBox2DRefinementModule
+    from simpb_amd.plugin.detection3d import SparseBox3DRefinementModule
+    g = torch.Generator().manual_seed(11)
+    n = 333
+    x = (torch.randn(1, n, 256, generator=g) * 1.5 + 0.2).cuda()
+    e = torch.randn(1, n, 256, generator=g).cuda()
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(256, generator=g))
+        ln.bias.copy_(0.1 * torch.randn(256, generator=g))
+    ln = ln.cuda()
+    ml = torch.tensor([live], dtype=torch.int32, device="cuda") if live is not None else None
+    rows = live if live is not None else n
+    with torch.no_grad():
+        if live is None:
+            ref3 = SparseBox3DRefinementModule(embed_dims=256, num_cls=10, refine_yaw=True, with_quality_estimation=True).cuda()
+            synth.load_procedural(ref3, seed=7)
+            anchor = torch.randn(1, n, 11, generator=g).cuda()
+            dt = torch.tensor([0.5], device="cuda")
+            want = ref3(dense.layernorm(x, ln), anchor, e, time_interval=dt, return_cls=True)
+            got = ref3(x, anchor, e, time_interval=dt, return_cls=True, norm=ln)
+            for a, b in zip(got, want):
+                assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+            assert float((ref3.norm_out - dense.layernorm(x, ln)).abs().max()) <= 1e-5
+        ref2 = SparseBox2DRefinementModule(embed_dims=256, with_alpha_branch=True).cuda()
+        synth.load_procedural(ref2, seed=3)
+        a2 = torch.rand(1, n, 2, generator=g).cuda()
+        xn = dense.layernorm(x, ln, m_live=ml)
+        want = ref2(xn, a2, e, m_live=ml)
+        got = ref2(x, a2, e, m_live=ml, norm=ln)
+        for a, b in zip(got, want):
+            if b is not None:
+                assert float((a[:, :rows] - b[:, :rows]).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+        assert float((ref2.norm_out - xn).abs().max()) <= 1e-5
+        if live is not None:
+            assert float(ref2.norm_out[:, live:].abs().max()) == 0.0

@@ -224,6 +224,36 @@ def test_pipelined_runner_overflow_with_a_decoder_already_enqueued_behind(split)
         assert int(runner.sticky.item()) == 0 and int(runner.hb.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_overflow_with_a_time_gap_frame_enqueued_behind_it(split):
+    """The chained hold and the track ids: frame 1 of the small golden stream overflows its (shrunk) slot array while the
+    decoder of frame 2 is already enqueued behind it -- and frame 2 is the one where stream 1 jumps in time, i.e. whose
+    InstanceBank.update resets that stream's track ids (instance_bank.py:147-149). That speculative frame must leave the ids
+    alone (the reset is gated by the hold, csrc/bank.hip): both frames are re-run in order on the state frame 0 left, and
+    every frame's detections and ids are the golden ones."""
+    g = load_golden("head_small.npz")
+    spec = spec_of(g)
+    assert spec["jump"] is not None and spec["jump"][1] == 2
+    model, runner = _golden_pipelined_runner(spec, split, capacity=96)
+    outs = []
+    for f in range(spec["frames"]):
+        if f == 1:
+            runner.capacity = runner.head.static_capacity = 16   # frame 1 (and the speculative frame 2) overflow
+            runner._drop_graphs()
+        model.stage(f)
+        torch.cuda.synchronize()
+        outs.append(runner.step(runner.img, synth.frame_metas(spec["bs"], f, spec["image_wh"], jump=spec["jump"])))
+    outs.append(runner.flush())
+    assert outs[0] is None and not runner.queue
+    assert runner.stats["overflow"] >= 1 and runner.capacity > 16, (runner.stats, runner.capacity)
+    for f in range(spec["frames"]):
+        for b in range(spec["bs"]):
+            compare_result(outs[f + 1][b]["img_bbox"], g, f"f{f}.res{b}.")
+    assert int(runner.flags.abs().sum()) == 0
+    if split:
+        assert int(runner.sticky.item()) == 0 and int(runner.hb.abs().sum()) == 0
+
+
 def test_split_runner_equals_two_stream_runner_bit_for_bit():
     """40 frames of synthetic features through PipelinedRunner and SplitPipelinedRunner (graphs, part A of
     frame t beside part B of frame t-1): the same launches on the same numbers, so every detection, score and track id must
