@@ -26,14 +26,18 @@ def main():
     ap.add_argument("--launches", type=int, default=3000)
     ap.add_argument("--cu-split", type=int, default=0)
     ap.add_argument("--anchors", type=int, default=900)
+    ap.add_argument("--build-flags", default="",
+                    help="extra hipcc flags for a variant build of the whole library (e.g. -fno-slp-vectorize: no packed-FP32 "
+                         "instructions in the victim kernel), combined with --k16 when both are given")
     args = ap.parse_args()
     import simpb_amd._lib as L
-    if args.k16:
+    if args.k16 or args.build_flags:
         from simpb_amd import build
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         os.makedirs(os.path.join(root, "gpurun_out", "k16"), exist_ok=True)
-        L.LIB = build.build_extension(extra_flags=["-DSIMPB_MFMA_F16_K16=1"],
-                                      out=os.path.join(root, "gpurun_out", "k16", "libsimpb_hip_k16.so"))
+        flags = (["-DSIMPB_MFMA_F16_K16=1"] if args.k16 else []) + args.build_flags.split()
+        L.LIB = build.build_extension(extra_flags=flags, out=os.path.join(root, "gpurun_out", "k16", "libsimpb_hip_variant.so"))
+        print("variant build:", flags, flush=True)
     from simpb_amd.plugin import ops
     from _streams import cu_masked_streams
     dev = torch.device("cuda")

@@ -10,7 +10,7 @@ NAMES = {"gemm_f32_kernel<64": "gemm_f32_kernel<64,4,64>", "gemm_f32_kernel<32, 
          "attention_f32_kernel<true": "attention_f32_kernel<true>", "mlp_chain_mfma": "mlp_chain_mfma_kernel",
          "mlp_chain_r4": "mlp_chain_r4_kernel", "linear_f32_mfma": "linear_f32_mfma", "linear_f16x3": "linear_f16x3 (value_proj)",
          "conv1x1_f16": "conv1x1_f16", "conv_staged_kernel<96, 128": "conv_staged<96,128> (FPN 3x3)", "conv_staged_kernel<96, 64": "conv_staged<96,64> (layer1 3x3)",
-         "conv_staged_kernel<128, 64": "conv_staged<128,64> (1x1, Cin >= 512)", "conv3x3_f16_kernel": "conv3x3 direct", "linear_h2": "linear_h2 (value_proj)"}
+         "conv_staged_kernel<128, 64": "conv_staged<128,64> (1x1, Cin >= 512)", "conv3x3_f16_kernel": "conv3x3 direct", "linear_h2": "linear_h2 (value_proj)", "stem_conv_pool": "stem_conv_pool (7x7 stem + pool)"}
 per = collections.defaultdict(dict)
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
@@ -36,7 +36,7 @@ for k, v in agg.items():
     print(k, out[k])
 json.dump(dict(
     command="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE "
-            "-- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline", round=2,
+            "-- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline",
     definition="mfma_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs) per dispatch, averaged "
                "(the guide's MfmaUtil): the share of SIMD cycles with a matrix instruction in flight, whatever its flop rate "
                "(v_mfma_f32_4x4x1f32 of mlp_chain_r4 keeps the pipe busy at a quarter of the 16x16x4 flop rate). "

@@ -21,7 +21,8 @@ KERNELS = {"daf_fwd_rows": "daf_fwd_rows", "msda_grouped_fwd": "msda_grouped_fwd
            "linear_f16x3_kernel": "linear_f16x3", "format_tokens_kernel": "format_tokens", "mlp_chain_mfma_kernel": "mlp_chain_mfma",
            "gemm_f32_kernel": "gemm_f32", "attention_f32_kernel": "attention_f32", "mlp_chain_r4_kernel": "mlp_chain_r4",
            "conv_staged_kernel": "conv_staged (3x3 / 1x1)", "conv3x3_f16_kernel": "conv3x3 direct", "linear_h2_kernel": "linear_h2 (value_proj)",
-           "alloc_static_kernel": "alloc_static"}
+           "alloc_static_kernel": "alloc_static", "daf_fused_rows": "daf_fused_rows", "msda_linear_fwd": "msda_linear_fwd",
+           "stem_conv_pool_kernel": "stem_conv_pool"}
 
 
 def find(root, pattern):
@@ -84,7 +85,7 @@ def main():
         kernels[short] = entry
     json.dump(dict(
         command=f"rocprofv3 --kernel-trace --stats / --kernel-trace --pmc FETCH_SIZE / --kernel-trace --pmc WRITE_SIZE (three separate passes) -- {command}",
-        round=2,
+        round=int(os.path.basename(out)[1:3]) if os.path.basename(out)[1:3].isdigit() else None,
         correction="traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes: FETCH_SIZE/WRITE_SIZE are in KB; gfx950 FETCH_SIZE counts half of the "
                    "bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are included in FETCH_SIZE; "
                    "averages over all dispatches of a kernel name in the pass",
