@@ -9,5 +9,12 @@ import os as _os
 # solver families off it picks its assembly implicit-GEMM kernels (igemm_fwd_gtcx35_nhwc_fp16 ... wt32x32x8: the older
 # instruction) and the same stress shows 0 of 600 (tools/daf_stress.py --co conv:256,256,32,88,3,1). The variables are
 # read by MIOpen when it first looks for a convolution solver, so they are set at import; a value the user exported wins.
+# Since round 3 a frame of the product path calls no vendor convolution at all (own stem, csrc/stem.hip; a GPU test patches
+# F.conv2d to raise); the switches below matter for the cross-check routes of the tests and for callers that run the
+# PyTorch statement of the backbone (routes.conv*_kernel = False) beside the decoder.
 for _name in ("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_FWD_XDLOPS", "MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_HIP_FWD_XDLOPS"):
-    _os.environ.setdefault(_name, "0")
+    if _os.environ.setdefault(_name, "0") != "0":
+        import warnings as _warnings
+        _warnings.warn(f"{_name}={_os.environ[_name]} (set outside simpb_amd): MIOpen may pick composable-kernel XDL convolution "
+                       "solvers, whose double-K matrix instructions corrupt other kernels running beside them on gfx950 "
+                       "(DESIGN.md section 4)", RuntimeWarning)
