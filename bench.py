@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--h2d", action="store_true",
                     help="frames start in pinned host memory and cross PCIe inside the timed step (async copy on the backbone "
                          "stream, beside the previous frame's decoder); default: inputs resident in HBM, as `value` requires")
+    ap.add_argument("--lib", default=None,
+                    help="measurement: load this build of the C-ABI library instead of the in-tree one (a variant built with "
+                         "other compiler flags: python -c 'from simpb_amd import build; build.build_extension(extra_flags=[...], out=PATH)')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=21, help="frames of the CPU baseline leg: 1 cold + the warm frames that are timed")
     return ap.parse_args()
@@ -288,6 +291,9 @@ def main():
     # the box's CPU share (a pool sized to the machine's core count stalls frames for tens of ms)
     torch.set_num_threads(max(1, min(4, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
 
+    if args.lib:
+        import simpb_amd._lib as _l
+        _l.LIB = os.path.abspath(args.lib)
     from simpb_amd.dist import DetectionGather
     from simpb_amd.runner import FrameRunner, PipelinedRunner, SplitPipelinedRunner
     torch.backends.cudnn.benchmark = not args.no_conv_search

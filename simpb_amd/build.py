@@ -13,6 +13,20 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libsimpb_hip.so")
 STAMP = LIB + ".srchash"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# The sampler / row kernels (plain vector arithmetic on gathered rows and small tables: every kernel that was ever recorded as
+# a VICTIM of the gfx950 double-K matrix instructions running elsewhere on the chip) are built without
+# packed-FP32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 come from the SLP and loop vectorisers). Round 3, one
+# run of tools/daf_stress.py: daf_fwd_rows beside a conv1x1 built on v_mfma_f32_32x32x16_f16 returned wrong channels in
+# 892-1 758 of 1 000-2 000 launches with packed FP32 and in 0 of 1 000 without (profiles/r02_mfma_x16_interference/README.md,
+# "Victim side"). The product issues no such matrix instruction any more; this keeps its vector kernels right beside a
+# foreign one as well. Costs nothing measurable in these latency-bound kernels (the whole library without SLP: +0.6 % per frame).
+NO_PACKED_FP32 = ["-fno-slp-vectorize", "-fno-vectorize"]
+ROW_KERNEL_FILES = ("deform_agg", "deform_agg_fused", "msda", "msda_lin", "alloc", "bank", "rowops", "dfa_prep", "decode", "format")
+
+
+def flags_for(src):
+    stem = os.path.basename(src)[:-4]
+    return FLAGS + (NO_PACKED_FP32 if stem in ROW_KERNEL_FILES else [])
 
 
 def sources():
@@ -28,6 +42,7 @@ def source_hash():
     for path in sources() + headers():
         with open(path, "rb") as f:
             h.update(f.read())
+    h.update(repr((FLAGS, NO_PACKED_FP32, ROW_KERNEL_FILES)).encode())   # a flag change is a rebuild as well
     return h.hexdigest()
 
 
@@ -52,7 +67,7 @@ def build_extension(force=False, verbose=False, jobs=None, extra_flags=(), out=N
 
     def compile_one(src):
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags_for(src) + list(extra_flags) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -1,4 +1,4 @@
-"""Two rules checked on the generated gfx950 ISA (hipcc -S cross-compiles without a GPU; skipped where there is no hipcc):
+"""Three rules checked on the generated gfx950 ISA (hipcc -S cross-compiles without a GPU; skipped where there is no hipcc):
 
 1. NO double-K matrix instruction anywhere in the product library. While a v_mfma_f32_32x32x16_f16 / 16x16x32_f16 (or
    their bf16 siblings, gfx950 only) executes anywhere on the chip, OTHER kernels' vector arithmetic goes wrong in lanes
@@ -11,7 +11,8 @@
    back-edges followed (a store at the end of one trip is in flight during the next trip's counted waits); the others
    (samplers, convolutions, backward kernels: grid-stride loops that prefetch across trips on purpose) get the
    straight-line reading only, as a regression guard; gemm.hip is exempt (its flagged store is the zero fill of a dead
-   tile behind a workgroup-uniform branch that returns right after)."""
+   tile behind a workgroup-uniform branch that returns right after).
+3. The sampler / row kernels are built without packed-FP32 instructions (test_row_kernels_carry_no_packed_fp32)."""
 import glob
 import os
 import shutil
@@ -52,6 +53,22 @@ def test_no_store_among_outstanding_loads(name, asm):
 def test_no_double_k_mfma_in_source_isa(name, asm):
     assert "v_mfma" in open(asm["gemm"]).read()  # the listing does contain matrix instructions: the scan is not vacuous
     assert not isa_store_scan.banned_mfma(asm[name])
+
+
+@needs_hipcc
+def test_row_kernels_carry_no_packed_fp32(asm):
+    """Rule 3 (victim side of rule 1, profiles/r02_mfma_x16_interference/README.md "Victim side"): the sampler / row kernels --
+    every kernel ever recorded as a victim of a double-K matrix instruction running elsewhere on the chip -- contain no
+    packed-FP32 instruction; with them daf_fwd_rows returned wrong channels in most launches beside such a kernel, without
+    them in none of 1 000 (simpb_amd/build.py: NO_PACKED_FP32, per file)."""
+    from simpb_amd import build
+    assert set(build.ROW_KERNEL_FILES) <= set(ALL_FILES)
+    for name in build.ROW_KERNEL_FILES:
+        text = open(asm[name]).read()
+        hits = sorted({m.group(0) for m in isa_store_scan.PACKED_FP32.finditer(text)})
+        assert not hits, (name, hits)
+    # (the scan does see the instruction where it is allowed: the matrix kernels' epilogues)
+    assert any(isa_store_scan.PACKED_FP32.search(open(asm[n]).read()) for n in ALL_FILES if n not in build.ROW_KERNEL_FILES)
 
 
 def test_no_double_k_mfma_in_built_library(tmp_path):

@@ -35,17 +35,23 @@ def hipcc():
     return None
 
 
+PACKED_FP32 = re.compile(r"\bv_pk_(fma|mul|add)_f32\b")
+
+
 def compile_all(out_dir, extra=()):
-    """hipcc -S (device only) of every csrc/*.hip into out_dir, in parallel; {stem: path of the .s}."""
+    """hipcc -S (device only) of every csrc/*.hip into out_dir with the flags the product build gives that file
+    (simpb_amd/build.py: flags_for), in parallel; {stem: path of the .s}."""
     cc = hipcc()
     if cc is None:
         raise FileNotFoundError("hipcc")
+    sys.path.insert(0, ROOT)
+    from simpb_amd import build
     srcs = sorted(glob.glob(os.path.join(ROOT, "simpb_amd", "csrc", "*.hip")))
 
     def one(src):
         s = os.path.join(out_dir, os.path.basename(src)[:-4] + ".s")
-        subprocess.run([cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", s, src] + list(extra),
-                       check=True, stderr=subprocess.DEVNULL)
+        flags = [f for f in build.flags_for(src) if f != "-fPIC"]
+        subprocess.run([cc] + flags + ["-S", "--cuda-device-only", "-o", s, src] + list(extra), check=True, stderr=subprocess.DEVNULL)
         return os.path.basename(src)[:-4], s
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
