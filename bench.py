@@ -391,10 +391,11 @@ def main():
             import glob
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sampler_traffic.json")), reverse=True):
                 try:
-                    return json.load(open(path))["kernels"][kernel]["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+                    entry = json.load(open(path))["kernels"][kernel]
+                    return entry["traffic_bytes_per_launch"], os.path.relpath(path, ROOT), (entry.get("rocprof") or {}).get("avg_us")
                 except (KeyError, ValueError):
                     continue
-            return None, None
+            return None, None, None
 
         tokens = 6 * sum((args.image_wh[1] // s) * (args.image_wh[0] // s) for s in (4, 8, 16, 32))
 
@@ -402,7 +403,7 @@ def main():
             feat_mb = tokens * 256 * k.get("feature_bytes_per_element", 4) / 1e6
             in_cache = feat_mb * 1e6 < 256 * 2 ** 20
             ach = k["nbytes"] / k["secs"] / 1e9
-            traffic, src = pmc_traffic(k["kernel"])
+            traffic, src, prof_us = pmc_traffic(k["kernel"])
             r = dict(kernel=k["kernel"], bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s",
                      frac=ach / HBM_PEAK_GBPS, traffic=traffic, avg_us=k["secs"] * 1e6, algorithmic_MB=k["nbytes"] / 1e6,
                      launches=k["launches"],
@@ -410,6 +411,9 @@ def main():
                      hbm_side_GBps=(traffic / k["secs"] / 1e9) if traffic else None,
                      hbm_side_frac=(traffic / k["secs"] / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                      traffic_source=src,
+                     # the same algorithmic bytes over the kernel's average duration under rocprofv3 --kernel-trace --stats of
+                     # this command (committed with the PMC passes; no launch latency in it, unlike the event interval above)
+                     rocprof_avg_us=prof_us, frac_at_rocprof_time=(k["nbytes"] / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if prof_us else None,
                      note=f"{what}; achieved = algorithmic bytes (SURVEY.md 8d) / launch time measured by HIP events on the "
                           f"launch stream in {k['launches']} instrumented launches right after the timed region; the feature "
                           f"set it reads is {feat_mb:.1f} MB and " + ("fits the 256 MiB Infinity Cache, so `achieved` is an on-die rate and can "
