@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--meter-frames", type=int, default=8, help="instrumented eager frames for the roofline leg")
     ap.add_argument("--no-conv-search", action="store_true",
                     help="do not let MIOpen benchmark convolution algorithms during warm-up (cudnn.benchmark off)")
+    ap.add_argument("--reference-batch", action="store_true",
+                    help="with --bs > 1: the reference's batch semantics (camera groups padded to the max over the batch, "
+                         "allocation.py:91-99) instead of bs independent streams decoded as batches of one")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent camera streams per GPU, each a bs-sized runner of its own replayed concurrently "
                          "(BASELINE config #3 shape: 8 streams per GPU)")
@@ -317,7 +320,7 @@ def main():
         model = build_model(args, device)
         runners.append(((SplitPipelinedRunner if split else PipelinedRunner) if pipelined else FrameRunner)(
             model, args.bs, (args.image_wh[1], args.image_wh[0]), capacity=args.capacity, device=device,
-            use_graph=not args.eager))
+            use_graph=not args.eager, independent_streams=not args.reference_batch))
     runner = runners[0]
     # N > 1: the fixed-shape device record of every stream to every rank, one all-gather per frame on a side stream
     gather = None
@@ -433,7 +436,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"simpb_nus_r{args.depth}_img_{args.image_wh[0]}x{args.image_wh[1]}: 6-cam frames, "
                                    f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, {args.streams} stream(s) x bs={args.bs} per GPU, temporal",
-                       "streams_per_gpu": args.bs * args.streams, "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "head_dtype": "f32 throughout (exact fp32 matrix instructions); the camera tokens are the fp16 backbone's output, sampled as they are and accumulated in f32", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
+                       "streams_per_gpu": args.bs * args.streams, "batch_semantics": ("one stream" if args.bs == 1 else "reference batch (groups padded to the max over the batch)" if args.reference_batch else f"{args.bs} independent streams per launch, each decoded as a batch of one (SURVEY.md 8e)"), "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "head_dtype": "f32 throughout (exact fp32 matrix instructions); the camera tokens are the fp16 backbone's output, sampled as they are and accumulated in f32", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
                        if world > 1 else "single GPU", "inputs": "pinned host frames, H2D inside the timed step" if args.h2d else "resident in HBM",
                        "fp16_matrix_step": "2 x v_mfma_f32_32x32x8f16 (csrc/mfma_f16.h)", "num_query2d_last_frame": n2, "frame_runner": mode},
             "roofline": roof, "roofline_msda": roof2,

@@ -424,6 +424,16 @@ int simpb_decode2d_record(float* rec2d, const float* cls2d, const float* box2d, 
                           const int* rank_of_anchor, int batch_size, int num_query2d, int num_classes, int num_anchors,
                           float crop_w, float crop_h, float crop_y0, float resize, void* stream);
 
+/* The 2D record for a batch of INDEPENDENT streams (simpb_alloc_ragged below): cls2d [slots, C], box2d [slots, 4], q2a and
+ * query_cam [slots] are the flat slot array, group_start i32 [bs * cams + 1] its group table, rank_of_anchor i32 [bs * A]
+ * (simpb_decode3d_record's output, indexed by the flat anchor b * A + a that q2a holds). rec2d f32 [bs, rows_per_stream, 8]:
+ * stream b's slots in its leading rows exactly as simpb_decode2d_record writes them for a batch of one (camera counted
+ * within the stream), pad rows (rank -1, camera -1) behind them. (decoder.py:168-175 per sample) */
+int simpb_decode2d_record_ragged(float* rec2d, const float* cls2d, const float* box2d, const int* q2a, const int* query_cam,
+                                 const int* group_start, const int* rank_of_anchor, int batch_size, int rows_per_stream,
+                                 int num_cams, int num_classes, int num_anchors, float crop_w, float crop_h, float crop_y0,
+                                 float resize, void* stream);
+
 /* Top-k of each score row, sorted descending (ties: lower index first): values f32 [bs, k], indices
  * i32 [bs, k] from scores f32 [bs, n], n <= 2048, k <= n. What `topk` of models/instance_bank.py:13-20
  * and the ranking of SparseBox3DDecoder.decode (models/detection3d/decoder.py:145-167) ask of torch.topk /
@@ -519,6 +529,22 @@ int simpb_alloc_static(unsigned char* flag, float* sel_xy, float* depth, int* co
                        int* overflow, float* ref_pts2d, float* ref_depth2d, int* q2a, int* is_center, int* a2q,
                        int* query_cam, const float* anchor, const float* projection_mat, int batch_size, int num_anchors,
                        int num_cams, int capacity, float img_w, float img_h, float limit_w, float limit_l, float limit_h,
+                       void* stream);
+
+/* The allocation for a batch of INDEPENDENT camera streams ("keep per-sample counts in the native path"):
+ * DynamicQueryAllocation.projection_allocation (models/allocation.py:27-144) pads every camera group to the max over the
+ * batch (:91-99), so a batch of streams with different headings carries ~3x the 2D slots a stream needs and attends the
+ * pads as keys; here every stream keeps the set a batch of one gives it. Steps 1-2 as simpb_alloc_static; step 3 lays the
+ * 2D set out as ONE flat slot array [batch_size * per_stream], stream-major then camera-major, live slots first:
+ *   group_start i32 [bs * cams + 1] (group g = b * cams + cam), query_cam i32 [slots] = g (or -1: capacity slot),
+ *   q2a i32 [slots] = b * num_anchors + a (or -1), is_center, ref_pts2d f32 [slots, 2], ref_depth2d f32 [slots],
+ *   a2q i32 [bs, A, cams] = flat slot (or -1); overflow[0] = 1 when a stream needs more than per_stream slots (clipped).
+ * The 2D operators then run as a batch of one over bs * cams camera groups (they take the group tables as they are),
+ * and the 3D side sees [1, bs * A, .] views. batch_size * num_cams <= 96. */
+int simpb_alloc_ragged(unsigned char* flag, float* sel_xy, float* depth, int* count, int* order, int* group_start,
+                       int* overflow, float* ref_pts2d, float* ref_depth2d, int* q2a, int* is_center, int* a2q,
+                       int* query_cam, const float* anchor, const float* projection_mat, int batch_size, int num_anchors,
+                       int num_cams, int per_stream, float img_w, float img_h, float limit_w, float limit_l, float limit_h,
                        void* stream);
 
 /* out[b, s, :] = src[b, q2a[b, s], :], zeros where q2a < 0: replaces

@@ -44,6 +44,7 @@ SIGNATURES = {
     "simpb_bank_cache": ([_P] * 10 + [_I] * 6 + [_F, _I, _F, _P, _I, _P, _P], _I),
     "simpb_decode3d_record": ([_P] * 6 + [_I] * 4 + [_P], _I),
     "simpb_decode2d_record": ([_P] * 6 + [_I] * 4 + [_F] * 4 + [_P], _I),
+    "simpb_decode2d_record_ragged": ([_P] * 7 + [_I] * 5 + [_F] * 4 + [_P], _I),
     "simpb_topk_rows": ([_P, _P, _P, _I, _I, _I, _P], _I),
     "simpb_rowdot_sigmoid": ([_P, _P, _I, _P, _P, _I, _I, _P, _P], _I),
     "simpb_anchor_projection": ([_P] * 4 + [_I] * 2 + [_P], _I),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "simpb_alloc_group_start": ([_P] * 3 + [_I] * 3 + [_P], _I),
     "simpb_alloc_scatter": ([_P] * 12 + [_I] * 4 + [_F] * 2 + [_P], _I),
     "simpb_alloc_static": ([_P] * 15 + [_I] * 4 + [_F] * 5 + [_P], _I),
+    "simpb_alloc_ragged": ([_P] * 15 + [_I] * 4 + [_F] * 5 + [_P], _I),
     "simpb_gather_rows": ([_P] * 3 + [_I] * 4 + [_P], _I),
     "simpb_aggregate_2d_to_3d": ([_P] * 8 + [_I] * 5 + [_P], _I),
     "simpb_aggregate_2d_to_3d_alpha": ([_P] * 9 + [_I, _I, _P, _P] + [_I] * 5 + [_P], _I),

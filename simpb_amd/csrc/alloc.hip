@@ -165,6 +165,74 @@ __global__ void alloc_scatter_kernel(float* __restrict__ ref_pts2d, float* __res
   is_center[idx] = ctr;
 }
 
+// ---- step 3, independent streams ("ragged" batch; SURVEY.md §8e: keep per-sample counts in the native path). The batch
+// holds bs independent camera streams, so nothing is padded to the max over the batch (allocation.py:91-99 would): the 2D
+// set is ONE flat slot array, stream-major then camera-major, group g = b * cams + cam holding count[g] slots; a slot's
+// q2a is the flat anchor index b * A + a, query_cam its group, and slots past the last group are capacity slots. Every
+// stream keeps exactly the set a batch of one would give it (at most `per_stream` slots; more sets the overflow flag and is
+// clipped). One thread per flat slot; the group table (prefix sums of the counts) is built per workgroup in LDS.
+constexpr int kMaxRaggedGroups = 96;
+__global__ __launch_bounds__(256) void alloc_scatter_ragged_kernel(
+    float* __restrict__ ref_pts2d, float* __restrict__ ref_depth2d, int* __restrict__ q2a, int* __restrict__ is_center,
+    int* __restrict__ a2q, int* __restrict__ query_cam, const int* __restrict__ count, const int* __restrict__ order,
+    const unsigned char* __restrict__ flag, const float* __restrict__ sel_xy, const float* __restrict__ depth, int bs, int A,
+    int cams, int per_stream, float img_w, float img_h, int* __restrict__ group_start_out, int* __restrict__ overflow_out) {
+  __shared__ int s_start[kMaxRaggedGroups + 1];
+  __shared__ int s_over;
+  const int G = bs * cams;
+  if (threadIdx.x == 0) {
+    int acc = 0, over = 0;
+    for (int b = 0; b < bs; ++b) {
+      int in_stream = 0;
+      for (int c = 0; c < cams; ++c) {
+        s_start[b * cams + c] = acc + in_stream;
+        in_stream += count[b * cams + c];
+        if (in_stream > per_stream) { over = 1; in_stream = per_stream; }
+      }
+      acc += in_stream;
+    }
+    s_start[G] = acc;
+    s_over = over;
+  }
+  __syncthreads();
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = bs * per_stream;
+  const int live = s_start[G];
+  int g = -1;
+  if (slot < live) {   // the last group whose start is <= slot (groups may be empty: equal starts)
+    int lo = 0, hi = G - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_start[mid] <= slot) lo = mid; else hi = mid - 1;
+    }
+    g = lo;
+  }
+  float x = 0.f, y = 0.f, d = 0.f;
+  int a = -1, ctr = 0, b = 0;
+  if (g >= 0) {
+    const int rank = slot - s_start[g];   // < s_start[g + 1] - s_start[g] <= count[g]
+    b = g / cams;
+    a = order[(size_t)g * A + rank];
+    const size_t o = (size_t)g * A + a;
+    x = sel_xy[2 * o] / img_w;
+    y = sel_xy[2 * o + 1] / img_h;
+    d = fabsf(depth[o]);
+    ctr = flag[o] == 2;
+  }
+  simpb::pin(x); simpb::pin(y); simpb::pin(d); simpb::pin(a); simpb::pin(ctr);
+  simpb::loads_retired();  // store_fence.h
+  if (blockIdx.x == 0 && threadIdx.x <= G) group_start_out[threadIdx.x] = s_start[threadIdx.x];
+  if (slot == 0) overflow_out[0] = s_over;
+  if (slot >= total) return;
+  query_cam[slot] = g;
+  if (a >= 0) a2q[((size_t)b * A + a) * cams + (g - b * cams)] = slot;
+  ref_pts2d[2 * (size_t)slot] = x;
+  ref_pts2d[2 * (size_t)slot + 1] = y;
+  ref_depth2d[slot] = d;
+  q2a[slot] = a >= 0 ? b * A + a : -1;
+  is_center[slot] = ctr;
+}
+
 // ---- device-side group table (allocation.py:91-99 without the .tolist()): group_start[c+1] =
 // sum over c' <= c of max over batch of count[b, c']; overflow[0] = 1 if the set exceeds capacity
 __global__ void alloc_group_start_kernel(int* __restrict__ group_start, int* __restrict__ overflow,
@@ -390,5 +458,28 @@ extern "C" int simpb_alloc_static(unsigned char* flag, float* sel_xy, float* dep
   hipLaunchKernelGGL(alloc_scatter_kernel, dim3((ns + 255) / 256), dim3(256), 0, s, ref_pts2d, ref_depth2d, q2a, is_center, a2q,
                      query_cam, static_cast<const int*>(nullptr), count, order, flag, sel_xy, depth, batch_size, num_anchors,
                      num_cams, capacity, img_w, img_h, group_start, overflow);
+  return status();
+}
+
+extern "C" int simpb_alloc_ragged(unsigned char* flag, float* sel_xy, float* depth, int* count, int* order, int* group_start,
+                                  int* overflow, float* ref_pts2d, float* ref_depth2d, int* q2a, int* is_center, int* a2q,
+                                  int* query_cam, const float* anchor, const float* projection_mat, int batch_size,
+                                  int num_anchors, int num_cams, int per_stream, float img_w, float img_h, float limit_w,
+                                  float limit_l, float limit_h, void* stream) {
+  if (!flag || !sel_xy || !depth || !count || !order || !group_start || !overflow || !ref_pts2d || !ref_depth2d || !q2a ||
+      !is_center || !a2q || !query_cam || !anchor || !projection_mat || batch_size <= 0 || num_anchors <= 0 ||
+      num_cams <= 0 || batch_size * num_cams > kMaxRaggedGroups || per_stream <= 0 ||
+      (long long)batch_size * per_stream > 0x7fffffffll / 4 || (long long)batch_size * num_anchors > 0x7fffffffll / 4)
+    return SIMPB_EINVAL;
+  clear_stale();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int n = batch_size * num_anchors * num_cams;
+  hipLaunchKernelGGL(alloc_project_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flag, sel_xy, depth, anchor, projection_mat,
+                     batch_size, num_anchors, num_cams, img_w, img_h, limit_w, limit_l, limit_h, a2q);
+  hipLaunchKernelGGL(alloc_compact_kernel, dim3(batch_size * num_cams), dim3(256), 0, s, count, order, flag, num_anchors);
+  const int ns = batch_size * per_stream;
+  hipLaunchKernelGGL(alloc_scatter_ragged_kernel, dim3((ns + 255) / 256), dim3(256), 0, s, ref_pts2d, ref_depth2d, q2a,
+                     is_center, a2q, query_cam, count, order, flag, sel_xy, depth, batch_size, num_anchors, num_cams, per_stream,
+                     img_w, img_h, group_start, overflow);
   return status();
 }

@@ -148,6 +148,54 @@ __global__ __launch_bounds__(256) void decode2d_kernel(float* __restrict__ rec2d
   *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
 }
 
+// The 2D half for a batch of independent streams (alloc.hip: alloc_scatter_ragged_kernel): the slot array is flat,
+// stream-major, group g = b * cams + cam; stream b's slots are group_start[b * cams] .. group_start[(b + 1) * cams). Writes
+// the same per-stream record a batch of one writes -- rec2d [bs, rows, 8], a stream's slots in its leading rows, camera
+// counted within the stream -- and pad rows (rank -1, camera -1) behind them. One thread per (stream, row); q2a holds flat
+// anchor indices b * A + a, which is also rank_of_anchor's index.
+__global__ __launch_bounds__(256) void decode2d_ragged_kernel(float* __restrict__ rec2d, const float* __restrict__ cls2d,
+                                                              const float* __restrict__ box2d, const int* __restrict__ q2a,
+                                                              const int* __restrict__ query_cam,
+                                                              const int* __restrict__ group_start,
+                                                              const int* __restrict__ rank_of_anchor, int bs, int rows, int cams,
+                                                              int C, int A, float crop_w, float crop_h, float crop_y0,
+                                                              float inv_resize) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs * rows) return;
+  const int b = i / rows, r_in = i - b * rows;
+  const int lo = group_start[b * cams], hi = group_start[(b + 1) * cams];
+  const bool live = lo + r_in < hi;
+  const int j = live ? lo + r_in : 0;   // (slot 0 is readable whenever anything is: clamped loads, zero-weighted below)
+  const float* row = cls2d + (size_t)j * C;
+  float m = row[0];
+  int arg = 0;
+  for (int c = 1; c < C; ++c)
+    if (row[c] > m) { m = row[c]; arg = c; }
+  const float* bx = box2d + (size_t)j * 4;
+  const float cx = bx[0], cy = bx[1], w = bx[2], h = bx[3];
+  float r[8];
+  r[0] = fminf(fmaxf((cx - 0.5f * w) * crop_w, 0.f), crop_w) * inv_resize;
+  r[1] = (fminf(fmaxf((cy - 0.5f * h) * crop_h, 0.f), crop_h) + crop_y0) * inv_resize;
+  r[2] = fminf(fmaxf((cx + 0.5f * w) * crop_w, 0.f), crop_w) * inv_resize;
+  r[3] = (fminf(fmaxf((cy + 0.5f * h) * crop_h, 0.f), crop_h) + crop_y0) * inv_resize;
+  r[4] = sigmoidf(m);
+  r[5] = (float)arg;
+  const int a = q2a[j];
+  r[6] = (a >= 0 && a < bs * A) ? (float)rank_of_anchor[a] : -1.f;
+  r[7] = (float)(query_cam[j] - b * cams);
+  if (!live) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[k] = 0.f;
+    r[6] = r[7] = -1.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) simpb::pin(r[k]);
+  simpb::loads_retired();  // store_fence.h
+  float* o = rec2d + (size_t)i * 8;
+  *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+}
+
 }  // namespace
 
 extern "C" int simpb_decode3d_record(float* rec3d, int* rank_of_anchor, const float* cls, const float* quality,
@@ -174,5 +222,21 @@ extern "C" int simpb_decode2d_record(float* rec2d, const float* cls2d, const flo
   hipLaunchKernelGGL(decode2d_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rec2d, cls2d,
                      box2d, q2a, query_cam, rank_of_anchor, batch_size, num_query2d, num_classes, num_anchors, crop_w, crop_h,
                      crop_y0, 1.f / resize);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_decode2d_record_ragged(float* rec2d, const float* cls2d, const float* box2d, const int* q2a,
+                                            const int* query_cam, const int* group_start, const int* rank_of_anchor,
+                                            int batch_size, int rows_per_stream, int num_cams, int num_classes, int num_anchors,
+                                            float crop_w, float crop_h, float crop_y0, float resize, void* stream) {
+  if (!rec2d || !cls2d || !box2d || !q2a || !query_cam || !group_start || !rank_of_anchor || batch_size <= 0 ||
+      rows_per_stream <= 0 || num_cams <= 0 || num_classes <= 0 || num_anchors <= 0 || resize == 0.f ||
+      (long long)batch_size * rows_per_stream > 0x7fffffffll / 8)
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  const int total = batch_size * rows_per_stream;
+  hipLaunchKernelGGL(decode2d_ragged_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rec2d,
+                     cls2d, box2d, q2a, query_cam, group_start, rank_of_anchor, batch_size, rows_per_stream, num_cams,
+                     num_classes, num_anchors, crop_w, crop_h, crop_y0, 1.f / resize);
   return simpb_check_launch();
 }

@@ -42,6 +42,12 @@ class AdaptiveQueryAggregation(nn.Module):
             raise NotImplementedError("denoising queries only exist in training")
         if allocation is None:
             allocation = _from_dense(trans_matrix, center_matrix)
+        a2q, shape3d = allocation.a2q, query3d.shape
+        if getattr(allocation, "streams", 0):
+            # a batch of independent streams: the 2D set is one flat slot array and a2q holds flat slots, so the 3D side
+            # joins it as [1, bs * N3, .] views (allocation.allocate_independent)
+            a2q = a2q.reshape(1, -1, a2q.shape[-1])
+            query3d, query_pos3d = query3d.reshape(1, -1, shape3d[-1]), query_pos3d.reshape(1, -1, shape3d[-1])
         if routes.R.dense and query2d.is_cuda and query2d.shape[-1] % 64 == 0 and allocation.is_center.dtype == torch.int32:
             # ReWeight (:10-40) in two launches: reduce over cat(query2d, is_center) as one GEMM whose
             # 257th input column is a flagged extra bias, then the alpha row-dot + sigmoid
@@ -50,16 +56,18 @@ class AdaptiveQueryAggregation(nn.Module):
             w_x, w_flag = dense.fold_split_last_column(red)
             hidden = dense.linear(query2d, w_x, red.bias, relu=True, m_live=m_live,
                                   row_flag=allocation.is_center.contiguous().reshape(-1), bias2=w_flag)
-            if allocation.a2q.shape[-1] <= 8:   # alpha = sigmoid(alp(hidden)) inside the aggregation launch
-                query3d, query_pos3d = aggregate_2d_to_3d(query3d, query_pos3d, query2d, query_pos2d, None, allocation.a2q,
+            if a2q.shape[-1] <= 8:   # alpha = sigmoid(alp(hidden)) inside the aggregation launch
+                query3d, query_pos3d = aggregate_2d_to_3d(query3d, query_pos3d, query2d, query_pos2d, None, a2q,
                                                           hidden=hidden, alpha_fc=alp)
+                query3d, query_pos3d = query3d.reshape(shape3d), query_pos3d.reshape(shape3d)
                 aggregated = graph_model(self.self_attn, query=query3d, query_pos=query_pos3d, attn_mask=attn_mask)
                 return aggregated, query_pos3d, anchor3d
             alpha = dense.rowdot_sigmoid(hidden, alp.weight, alp.bias, m_live=m_live)
         else:
             center_param = torch.cat([query2d, allocation.is_center[..., None].to(query2d.dtype)], dim=-1)
             alpha = self.reweight(center_param)
-        query3d, query_pos3d = aggregate_2d_to_3d(query3d, query_pos3d, query2d, query_pos2d, alpha, allocation.a2q)
+        query3d, query_pos3d = aggregate_2d_to_3d(query3d, query_pos3d, query2d, query_pos2d, alpha, a2q)
+        query3d, query_pos3d = query3d.reshape(shape3d), query_pos3d.reshape(shape3d)
         aggregated = graph_model(self.self_attn, query=query3d, query_pos=query_pos3d, attn_mask=attn_mask)
         return aggregated, query_pos3d, anchor3d
 

@@ -21,10 +21,18 @@ class Allocation2D:
     ref_center_matrix / query_groups."""
 
     __slots__ = ("q2a", "is_center", "a2q", "query_cam", "query_groups", "num_anchor", "count", "group_start",
-                 "overflow")
+                 "overflow", "streams")
+
+    def __init__(self):
+        # 0: the reference's batch layout [bs, N2] (groups padded to the max over the batch). bs > 0: a batch of that many
+        # INDEPENDENT streams as one flat slot array [1, bs * capacity] over bs * cams groups (csrc/alloc.hip:
+        # alloc_scatter_ragged_kernel); q2a then holds flat anchor indices b * num_anchor + a
+        self.streams = 0
 
     def dense(self):
         """The reference's (trans_matrix, center_matrix) one-hot f32 [bs, N2, N3] (allocation.py:128-142)."""
+        if self.streams:
+            raise NotImplementedError("a batch of independent streams has no [bs, N2, N3] matrix form")
         bs, n2 = self.q2a.shape
         trans = torch.zeros(bs, n2, self.num_anchor + 1, device=self.q2a.device)
         idx = torch.where(self.q2a >= 0, self.q2a, self.num_anchor).long()
@@ -46,13 +54,69 @@ class DynamicQueryAllocation(nn.Module):
         self.limit_corners_num = limit_corners_num
         self.last = None
 
-    def forward(self, anchor3d, metas, dense=True, capacity=None, overflow_out=None):
+    def forward(self, anchor3d, metas, dense=True, capacity=None, overflow_out=None, independent=False):
         """Returns the reference's 8-tuple (allocation.py:144). With dense=True the two one-hot
         matrices are materialised from the index form; with dense=False their places hold None
         and callers use `self.last` (an Allocation2D) instead."""
+        if independent:
+            alloc, ref_pts2d, ref_depth2d = self.allocate_independent(anchor3d, metas, capacity, overflow_out)
+            if dense:
+                raise ValueError("independent streams: index form only (dense=False)")
+            return ref_pts2d, ref_depth2d, None, None, None, None, None, None
         alloc, ref_pts2d, ref_depth2d, trans_mask, trans_shape = self.allocate(anchor3d, metas, capacity, overflow_out)
         trans, center = alloc.dense() if dense else (None, None)
         return ref_pts2d, ref_depth2d, trans_mask, trans_shape, trans, center, alloc.query_groups, None
+
+    def allocate_independent(self, anchor3d, metas, capacity, overflow_out=None):
+        """The batch as `bs` independent camera streams: every stream keeps the 2D set a batch of one gives
+        it, at most `capacity` slots each; one flat slot array [1, bs * capacity] over bs * cams groups, live slots first
+        (Allocation2D.streams = bs). Static shapes only."""
+        if self.training:
+            raise NotImplementedError("training-time corner sampling (allocation.py:85-87) is not on this path")
+        if capacity is None:
+            raise ValueError("independent streams need a static capacity (slots per stream)")
+        _require_gpu(anchor3d)
+        lib = _lib.lib()
+        anchor3d = anchor3d.contiguous().float()
+        proj = metas["projection_mat"].contiguous().float()
+        bs, num_anchor = anchor3d.shape[:2]
+        cams = proj.shape[1]
+        if anchor3d.shape[-1] != 11 or tuple(proj.shape) != (bs, cams, 4, 4):
+            raise ValueError("anchor3d must be [bs, N, 11] and projection_mat [bs, cams, 4, 4]")
+        wh = metas.get("image_wh_host")
+        if wh is None:
+            wh = tuple(int(v) for v in metas["image_wh"][0, 0].tolist())
+        img_w, img_h = float(wh[0]), float(wh[1])
+        dev = anchor3d.device
+        lw, ll, lh = (float(v) for v in self.limit_anchor_size)
+        slots = bs * int(capacity)
+        flag = torch.empty(bs, cams, num_anchor, dtype=torch.uint8, device=dev)
+        sel_xy = torch.empty(bs, cams, num_anchor, 2, device=dev)
+        depth = torch.empty(bs, cams, num_anchor, device=dev)
+        overflow = overflow_out if overflow_out is not None else torch.empty(1, dtype=torch.int32, device=dev)
+        if overflow.dtype != torch.int32 or overflow.numel() != 1 or overflow.device != dev:
+            raise ValueError("overflow_out must be one i32 element on the anchors' device")
+        out = Allocation2D()
+        out.streams = bs
+        out.count = torch.empty(bs, cams, dtype=torch.int32, device=dev)
+        order = torch.empty(bs, cams, num_anchor, dtype=torch.int32, device=dev)
+        out.group_start = torch.empty(bs * cams + 1, dtype=torch.int32, device=dev)
+        ref_pts2d = torch.empty(1, slots, 2, device=dev)
+        ref_depth2d = torch.empty(1, slots, 1, device=dev)
+        out.q2a = torch.empty(1, slots, dtype=torch.int32, device=dev)
+        out.is_center = torch.empty(1, slots, dtype=torch.int32, device=dev)
+        out.a2q = torch.empty(bs, num_anchor, cams, dtype=torch.int32, device=dev)
+        out.query_cam = torch.empty(slots, dtype=torch.int32, device=dev)
+        out.query_groups = None
+        out.num_anchor = num_anchor
+        out.overflow = overflow
+        _lib.check(lib.simpb_alloc_ragged(_ptr(flag), _ptr(sel_xy), _ptr(depth), _ptr(out.count), _ptr(order),
+                                          _ptr(out.group_start), _ptr(overflow), _ptr(ref_pts2d), _ptr(ref_depth2d),
+                                          _ptr(out.q2a), _ptr(out.is_center), _ptr(out.a2q), _ptr(out.query_cam), _ptr(anchor3d),
+                                          _ptr(proj), bs, num_anchor, cams, int(capacity), img_w, img_h, lw, ll, lh, _stream()),
+                   "simpb_alloc_ragged")
+        self.last = out
+        return out, ref_pts2d, ref_depth2d
 
     def allocate(self, anchor3d, metas, capacity=None, overflow_out=None):
         """capacity=None: size the 2D set exactly (one count readback, like allocation.py:94).

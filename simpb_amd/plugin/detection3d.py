@@ -378,6 +378,8 @@ class SparseBox3DDecoder(object):
                 and self.num_output <= 512 and box3.shape[-1] == 11 and alloc.q2a.dtype == torch.int32):
             return self._decode_static_fused(cls3, box3, instance_id, qulity[output_idx] if qulity is not None else None,
                                              cls_scores2d[output_idx2d], box_preds2d[output_idx2d], alloc, aug_config)
+        if getattr(alloc, "streams", 0):
+            raise NotImplementedError("a batch of independent streams is decoded by the device kernels (csrc/decode.hip) only")
         scores, origin, cls_ids, indices, mask, num_cls = self._rank(cls_scores, qulity, output_idx, True)
         if mask is not None:
             raise NotImplementedError("score_threshold with the static decoder")
@@ -419,8 +421,21 @@ class SparseBox3DDecoder(object):
                                              _stream()), "simpb_decode3d_record")
         cls2d, box2d = cls2d.contiguous().float(), box2d.contiguous().float()
         n2 = cls2d.shape[1]
-        rec2d = torch.empty(bs, n2, 8, device=dev)
         crop, resize = aug_config["crop"], aug_config["resize"]
+        if getattr(alloc, "streams", 0):
+            # independent streams: the flat slot array [1, bs * capacity] back to one record per stream, as a batch of one
+            # writes it (its slots first, cameras counted within the stream, pad rows behind)
+            if alloc.streams != bs or n2 % bs:
+                raise ValueError("decode: the allocation does not belong to this batch")
+            rows = n2 // bs
+            rec2d = torch.empty(bs, rows, 8, device=dev)
+            cams = (alloc.group_start.numel() - 1) // bs
+            _lib.check(lib.simpb_decode2d_record_ragged(
+                _ptr(rec2d), _ptr(cls2d), _ptr(box2d), _ptr(alloc.q2a.contiguous()), _ptr(alloc.query_cam.contiguous()),
+                _ptr(alloc.group_start), _ptr(rank), bs, rows, cams, cls2d.shape[-1], num_anchor, float(crop[2] - crop[0]),
+                float(crop[3] - crop[1]), float(crop[1]), float(resize), _stream()), "simpb_decode2d_record_ragged")
+            return rec3d, rec2d
+        rec2d = torch.empty(bs, n2, 8, device=dev)
         if n2:
             _lib.check(lib.simpb_decode2d_record(_ptr(rec2d), _ptr(cls2d), _ptr(box2d), _ptr(alloc.q2a.contiguous()),
                                                  _ptr(alloc.query_cam.contiguous()), _ptr(rank), bs, n2, cls2d.shape[-1],
@@ -429,12 +444,16 @@ class SparseBox3DDecoder(object):
         return rec3d, rec2d
 
     @staticmethod
-    def decode_static_host(rec3d, rec2d, num_cams=6):
+    def decode_static_host(rec3d, rec2d, num_cams=6, independent=False):
         """Host half: the reference's per-sample dict (decoder.py:176-251) from the two records.
         Plain numpy on purpose: these are a few hundred elements, and CPU tensor ops would wake
-        torch's intra-op thread pool once per call (measured: 50 ms stalls on a shared box)."""
+        torch's intra-op thread pool once per call (measured: 50 ms stalls on a shared box).
+        independent: the records are those of independent streams (SimPBHead.independent_streams): each is decoded as
+        the batch of one it is, instead of with the group table of sample 0 carried along the batch (:216)."""
         import numpy as np
         rec3d, rec2d = np.asarray(rec3d), np.asarray(rec2d)
+        if independent and len(rec3d) > 1:
+            return [SparseBox3DDecoder.decode_static_host(rec3d[i:i + 1], rec2d[i:i + 1], num_cams)[0] for i in range(len(rec3d))]
         cam_all = rec2d[0][:, 7].astype(np.int64)
         query_groups, start = [], 0
         for c in range(num_cams):  # slots are camera-major: group c = the run of slots with camera c

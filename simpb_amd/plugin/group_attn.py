@@ -123,7 +123,9 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
         w, b = dense.fold_stack("msda_in", [self.sampling_offsets, self.attention_weights], copies=2)
         both = dense.linear([query, query_pos], w, b, m_live=m_live)
         tokens = value_f16 if value_f16 is not None and value_f16.shape == value.shape else value
-        tokens = tokens.reshape(bs, self.num_cams, -1, self.embed_dims)
+        # (a batch of independent streams arrives as ONE flat 2D set over all the streams' cameras: bs = 1 here and
+        # value.shape[0] = streams x num_cams camera groups, allocation.allocate_independent)
+        tokens = tokens.reshape(bs, value.shape[0] // bs, -1, self.embed_dims)
         agg = msda_linear(tokens.contiguous(), spatial_shapes, level_start_index, both, reference_points, query_cam, m_live)
         wf, bf = dense.fold_msda_linear(self.value_proj, self.output_proj, self.num_heads, MSDA_LINEAR_WIDTH)
         output = dense.report(self.output_proj, dense.linear(agg, wf, bf, m_live=m_live))
@@ -153,7 +155,7 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
         linear_route = (routes.R.msda_linear and routes.R.dense and not value_is_projected and query.is_cuda and query_pos is not None
                         and self.batch_first and query.shape == query_pos.shape and key_padding_mask is None
                         and (self.num_heads, self.num_levels, self.num_points, self.embed_dims) == (8, 4, 4, 256)
-                        and reference_points.shape[-1] == 2 and value.dim() == 3 and value.shape[0] == bs * self.num_cams
+                        and reference_points.shape[-1] == 2 and value.dim() == 3 and value.shape[0] % (bs * self.num_cams) == 0
                         and value.shape[-1] == 256 and query_cam is not None)
         if linear_route:
             return self._forward_linear(raw_query, query_pos, identity, value, kwargs.get("value_f16"), reference_points,

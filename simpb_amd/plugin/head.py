@@ -110,6 +110,11 @@ class SimPBHead(BaseModule):
         # behaviour). An int: static shapes with that many 2D slots and no host round trip inside
         # the frame, which is what lets simpb_amd.runner replay the frame as one hipGraph.
         self.static_capacity = None
+        # True (static capacity only): the batch is a set of INDEPENDENT camera streams -- every stream keeps the 2D query
+        # set a batch of one gives it, laid out as one flat slot array (allocation.allocate_independent),
+        # instead of the reference's groups padded to the max over the batch (allocation.py:91-99). False: the reference's
+        # batch semantics.
+        self.independent_streams = False
 
     def init_weights(self):
         """simpb_head.py:202-212."""
@@ -330,11 +335,16 @@ class SimPBHead(BaseModule):
             elif op == "allocation":
                 assert self.instance_status == "3d"
                 k = len(ref_pts2d_list)
+                ragged = self.independent_streams and cap is not None and batch_size > 1
                 anchor2d, ref_depth2d, ref_trans_mask, ref_trans_shape, _, _, ref_query_groups, _ = layer(
                     anchor, metas, dense=False, capacity=cap,
-                    overflow_out=overflow[k:k + 1] if overflow is not None else None)
+                    overflow_out=overflow[k:k + 1] if overflow is not None else None, independent=ragged)
                 alloc = layer.last
-                if cap is not None and batch_size == 1 and alloc.group_start is not None:
+                if ragged:   # one flat slot array over batch_size * num_cams groups: the 2D operators run as a batch of one
+                    groups = batch_size * self.num_cams
+                    self._m_live = alloc.group_start[groups: groups + 1]
+                    instance_feature = instance_feature.reshape(1, -1, instance_feature.shape[-1])
+                elif cap is not None and batch_size == 1 and alloc.group_start is not None:
                     self._m_live = alloc.group_start[self.num_cams: self.num_cams + 1]
                 instance_feature = gather_rows(instance_feature, alloc.q2a)  # :438
                 anchor_embed2d = (self.anchor_encoder2d(anchor2d, m_live=self._m_live) if self._m_live is not None

@@ -23,10 +23,15 @@ from .plugin.detection3d import SparseBox3DDecoder
 
 
 class FrameRunner:
-    def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True):
+    def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True, independent_streams=False):
+        """independent_streams: the batch is a set of independent camera streams, each decoded exactly as a batch of one
+        would be (`capacity` 2D slots per stream; SimPBHead.independent_streams) -- the throughput form of BASELINE config
+        #3. False: the reference's batch semantics (camera groups padded to the max over the batch)."""
         self.model = model
         self.head = model.head
         self.bs = batch_size
+        self.independent = bool(independent_streams) and batch_size > 1
+        self.head.independent_streams = self.independent
         self.capacity = int(capacity)
         self.use_graph = use_graph
         self.device = device if device is not None else next(model.parameters()).device
@@ -153,7 +158,7 @@ class FrameRunner:
         self.last_rec3d, self.last_rec2d = rec[0], rec[1]
         self.prev_metas = dict(img_metas=metas["img_metas"])
         self.head.instance_bank.metas = self.prev_metas
-        results = SparseBox3DDecoder.decode_static_host(rec3d.numpy(), rec2d.numpy(), self.head.num_cams)
+        results = SparseBox3DDecoder.decode_static_host(rec3d.numpy(), rec2d.numpy(), self.head.num_cams, self.independent)
         return [{"img_bbox": r} for r in results]
 
 
@@ -175,8 +180,8 @@ class PipelinedRunner(FrameRunner):
     is chained on the device: a frame's commit also holds back when the flags of the frame enqueued before it are
     set (`overflow_chain`, plugin/head.py), and collect() then re-runs both, in order, on the state frame t-1 found."""
 
-    def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True):
-        super().__init__(model, batch_size, image_hw, capacity, device, use_graph)
+    def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True, independent_streams=False):
+        super().__init__(model, batch_size, image_hw, capacity, device, use_graph, independent_streams)
         dev = self.device
         # the decoder of frame t is the critical path (a chain of ~170 dependent small launches); the
         # backbone of frame t+1 only has to be done by the time that chain ends: decoder stream first
@@ -350,7 +355,7 @@ class PipelinedRunner(FrameRunner):
                 self.queue.append(self._enqueue_decoder(b["slot"], b["metas"], b["prev"], True))
         self.last_rec3d, self.last_rec2d = job["rec"][0], job["rec"][1]
         self.prev_metas = dict(img_metas=job["metas"]["img_metas"])
-        results = SparseBox3DDecoder.decode_static_host(h[0].numpy(), h[1].numpy(), self.head.num_cams)
+        results = SparseBox3DDecoder.decode_static_host(h[0].numpy(), h[1].numpy(), self.head.num_cams, self.independent)
         return [{"img_bbox": r} for r in results]
 
     def _quiesce(self):
@@ -408,8 +413,8 @@ class SplitPipelinedRunner(PipelinedRunner):
         backbone stream, so no tensor of the caching allocator crosses streams.
     """
 
-    def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True):
-        super().__init__(model, batch_size, image_hw, capacity, device, use_graph)
+    def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True, independent_streams=False):
+        super().__init__(model, batch_size, image_hw, capacity, device, use_graph, independent_streams)
         dev = self.device
         # part A rides on the backbone stream, right behind backbone(t): as fast for one stream as a third stream of its own
         # (350 frames/s either way) and cheaper when several runners share the GPU (8 runners: 368 against 308 frames/s)

@@ -84,6 +84,51 @@ def test_static_allocation_call_equals_the_stepwise_kernels(bs, capacity):
     assert int(outs[0][6].item()) == (1 if capacity == 600 else 0)
 
 
+@pytest.mark.parametrize("bs,capacity", [(3, 1536), (8, 1280), (2, 600)])
+def test_allocation_of_independent_streams_equals_batches_of_one(bs, capacity):
+    """simpb_alloc_ragged (per-sample counts in the native path): a batch of independent streams laid out as
+    one flat slot array must hold, stream by stream, exactly the tables the pinned static call gives a batch of one
+    (allocation.py:27-144 at bs = 1) -- slots shifted by the streams in front, anchors by b * N3, cameras by b * cams --
+    and nothing else; the overflow case (capacity 600 < N2) clips every stream like a batch of one."""
+    from simpb_amd.plugin import allocation
+    layer = allocation.DynamicQueryAllocation().eval()
+    metas = metas_to(synth.frame_metas(bs, 0), "cuda")
+    g = torch.Generator().manual_seed(bs)
+    anchor = torch.from_numpy(synth.anchors(900)).float()[None].repeat(bs, 1, 1)
+    anchor[..., :2] += torch.randn(bs, 900, 2, generator=g) * 3.0
+    yaw = torch.rand(bs, generator=g) * 6.28   # streams look in different directions: different cameras fill up
+    xy = anchor[..., :2].clone()
+    anchor[..., 0] = xy[..., 0] * yaw.cos()[:, None] - xy[..., 1] * yaw.sin()[:, None]
+    anchor[..., 1] = xy[..., 0] * yaw.sin()[:, None] + xy[..., 1] * yaw.cos()[:, None]
+    anchor = anchor.cuda()
+    r, pts, depth = layer.allocate_independent(anchor, metas, capacity)
+    assert r.streams == bs and tuple(r.q2a.shape) == (1, bs * capacity) and tuple(pts.shape) == (1, bs * capacity, 2)
+    gs = r.group_start.cpu().numpy()
+    q2a, ctr, cam = r.q2a[0].cpu().numpy(), r.is_center[0].cpu().numpy(), r.query_cam.cpu().numpy()
+    a2q = r.a2q.cpu().numpy()
+    pts, depth = pts[0].cpu().numpy(), depth[0, :, 0].cpu().numpy()
+    assert gs[0] == 0 and (np.diff(gs) >= 0).all()
+    any_over = 0
+    for b in range(bs):
+        one = {k: (v[b:b + 1] if torch.is_tensor(v) else v) for k, v in metas.items() if k != "img_metas"}
+        s, spts, sdepth, _, _ = layer.allocate(anchor[b:b + 1], one, capacity=capacity)
+        lo, hi = int(gs[b * 6]), int(gs[(b + 1) * 6])
+        n = int(s.group_start[6].item())
+        any_over |= int(s.overflow.item())
+        assert hi - lo == n, (b, lo, hi, n)
+        assert np.array_equal(gs[b * 6: b * 6 + 7] - lo, s.group_start.cpu().numpy())
+        sq = s.q2a[0, :n].cpu().numpy()
+        assert np.array_equal(q2a[lo:hi], np.where(sq >= 0, sq + b * 900, -1))
+        assert np.array_equal(ctr[lo:hi], s.is_center[0, :n].cpu().numpy())
+        assert np.array_equal(cam[lo:hi], s.query_cam[:n].cpu().numpy() + b * 6)
+        assert np.array_equal(pts[lo:hi], spts[0, :n].cpu().numpy()) and np.array_equal(depth[lo:hi], sdepth[0, :n, 0].cpu().numpy())
+        sa = s.a2q[0].cpu().numpy()
+        assert np.array_equal(a2q[b], np.where(sa >= 0, sa + lo, -1))
+    live = int(gs[-1])
+    assert (q2a[live:] == -1).all() and (cam[live:] == -1).all() and (ctr[live:] == 0).all()
+    assert int(r.overflow.item()) == any_over == (1 if capacity == 600 else 0)
+
+
 def test_msda_module_vs_reference_vectors():
     """A6: QueryGroupMultiScaleDeformableAttention (product module: projections + msda_prep + grouped sampler kernel +
     output_proj + cat) against the reference's own per-camera loop output (ops.npz:msda.out)."""

@@ -20,6 +20,11 @@ while "--route" in sys.argv:
     _stack.enter_context(routes.override(**{k: bool(int(v))}))
     del sys.argv[i:i + 2]
 print("routes:", routes.R, flush=True)
+BS = 1
+if "--bs" in sys.argv:   # --bs N: N camera streams through one batched runner
+    i = sys.argv.index("--bs")
+    BS = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 wh = (704, 256)
 cfg = configs.simpb_plus(anchor=synth.anchors(900))
 model = plugin.build_detector(cfg["model"]).eval()
@@ -30,7 +35,11 @@ if "--prio" in sys.argv:   # --prio BB HEAD: stream priorities of the backbone /
     i = sys.argv.index("--prio")
     PipelinedRunner.STREAM_PRIORITIES = (int(sys.argv[i + 1]), int(sys.argv[i + 2]))
     print("stream priorities (backbone, decoder):", PipelinedRunner.STREAM_PRIORITIES, torch.cuda.Stream.priority_range(), flush=True)
-r = PipelinedRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"))
+REF_BATCH = "--reference-batch" in sys.argv   # bs > 1 with the reference's padded camera groups instead of independent streams
+if REF_BATCH:
+    sys.argv.remove("--reference-batch")
+r = PipelinedRunner(model, BS, (wh[1], wh[0]), capacity=1536 if BS == 1 or not REF_BATCH else 2048, device=torch.device("cuda"),
+                    independent_streams=not REF_BATCH)
 DEC_ONLY = "--dec-only" in sys.argv   # for rocprofv3 --kernel-trace: decoder graph replays with nothing beside them
 if len(sys.argv) > 1 and not DEC_ONLY and "--bb-only" not in sys.argv and "--co" not in sys.argv and "--prio" not in sys.argv:
     # --bb-drop N: the backbone stream loses one group of 8 CUs in every N groups (in every XCD, whichever way CU indices
@@ -50,8 +59,8 @@ if len(sys.argv) > 1 and not DEC_ONLY and "--bb-only" not in sys.argv and "--co"
     assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), m) == 0
     r.s_bb = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", 0))
     print(f"backbone stream on {kept} of {n_cu} CUs", flush=True)
-imgs = [synth.images(1, f, wh).cuda() for f in range(4)]
-metas = [synth.frame_metas(1, f, wh) for f in range(60)]
+imgs = [synth.images(BS, f, wh).cuda() for f in range(4)]
+metas = [synth.frame_metas(BS, f, wh) for f in range(60)]
 for f in range(24):
     r.step(imgs[f % 4], metas[f])
 torch.cuda.synchronize()
@@ -131,4 +140,4 @@ if "--bb-only" in sys.argv:   # for rocprofv3 --kernel-trace: backbone graph rep
     sys.exit(0)
 for name, fn in (("backbone graph alone", bb), ("decoder graph alone", dec), ("both streams side by side", both)):
     fn()
-    print(f"{name:28s} {wall(fn):.3f} ms per frame", flush=True)
+    print(f"{name:28s} {wall(fn):.3f} ms per step of {BS} frame(s)", flush=True)
