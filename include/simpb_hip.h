@@ -309,7 +309,7 @@ int simpb_attention_f32(float* out, const float* q, const float* k, const float*
  *                 IN_ROWS_LN input = LayerNorm(x) * ln_w + ln_b (eps 1e-5) + x2: the decoder's `norm` operator in front of
  *                            a refinement head (models/simpb_head.py operation_order "norm", "refine*") inside the head's
  *                            launch; ln_out (row stride ld_ln_out, may be NULL) receives LayerNorm(x), the operator's
- *                            own output (rows >= *m_live as zeros). 4-row kernel (weights_transposed == 2) only.
+ *                            own output (rows >= *m_live as zeros). 4-row / 32-row kernels (weights_transposed == 2, 3) only.
  *   chain output: out rows of the last width, row stride ldo; out_scale (or NULL) multiplies column-wise
  *                 (mmcv Scale after the last Linear); then the optional `post` stage on v = out[row, t]:
  *     POST_REFINE3D  SparseBox3DRefinementModule.forward (models/detection3d/blocks.py:133-143):
@@ -353,7 +353,11 @@ typedef struct simpb_mlp_args {
   int num_rows, num_chains;
   int weights_transposed;  /* 0: LINEAR.w is nn.Linear's [out_dim, in_dim] (16-row MFMA kernel); 1: [in_dim, out_dim] (VALU
                             * kernel); 2: k4-packed [in_dim / 4][out_dim][4] for layers with in_dim % 4 == 0, nn.Linear's
-                            * layout for the others (4-row kernel on the 4x4 matrix blocks: 225 workgroups for 900 rows) */
+                            * layout for the others (4-row kernel on the 4x4 matrix blocks: 225 workgroups for 900 rows);
+                            * 3: fragment-packed [ceil(out_dim / 32)][in_dim / 32][4][64][4] for layers with in_dim % 32 == 0
+                            * -- element [t][c][q][32 h + r][e] = W[32 t + r][32 c + 16 h + 4 q + e], zeros past out_dim --
+                            * nn.Linear's layout for the others (32-row kernel on the 32x32 matrix tiles: launches with
+                            * thousands of rows, i.e. a batch of camera streams) */
   int reserved;
   simpb_mlp_chain chain[SIMPB_MLP_MAX_CHAINS];
   const int* m_live;       /* device int or NULL: rows >= *m_live are capacity slots of the static 2D query set; workgroups

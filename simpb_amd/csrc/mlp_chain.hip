@@ -272,6 +272,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_chain_kernel(simpb_mlp_args ar
 // scattered 16-byte pieces per row = 32 lines per wave-load). A and B use the same permutation, so
 // the sum is unchanged.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kMR = 16, kMW = 8;
 
 // compile-time loop (register-set indices must be constants in the front end: csrc/gemm.hip)
@@ -707,6 +708,238 @@ __global__ __launch_bounds__(256) void mlp_chain_r4_kernel(simpb_mlp_args args) 
   }
 }
 
+// ---- 32-row variant on the 32x32 matrix tiles (weights_transposed == 3), for launches with thousands of rows (a batch of
+// camera streams per launch, runner independent_streams). The 4-row kernel above exists to spread ~1 k rows over 256 CUs; its
+// v_mfma_f32_4x4x1f32 issues at a quarter of the fp32 matrix rate, and at ~9 k rows (bs = 8) that IS the bound: measured
+// 33-36 TFLOP/s on every chain (refine2d 213 us, 2D encoder 64 us, per step of 8 frames), the 4x4x1 issue peak. Here:
+//   one workgroup = 32 rows x 4 waves; the row tile lives in LDS between layers (two buffers, 66 KB: two workgroups per CU);
+//   wave w owns output columns 64w..64w+63 = two 32x32 tiles of v_mfma_f32_32x32x2f32 (full fp32 matrix rate);
+//   lane (r32, half) holds k = 16 * half + 0..15 of a 32-deep chunk of its A row (LDS, four ds_read_b128) and of its B
+//   column (the same k permutation on both operands, as in csrc/gemm.hip), sixteen matrix steps per tile and chunk;
+//   weights arrive FRAGMENT-PACKED by the host (plugin/fused.py): Wq[tile][chunk][q][lane][4] = W[32 tile + r32][32 chunk +
+//   16 half + 4 q + 0..3], columns past out_dim as zeros -- a wave's B operand of a chunk is four fully coalesced 1-KiB
+//   loads straight into registers (no staging, no barrier inside a layer), two chunks in flight, every request
+//   unconditional with a clamped index so that the waits are counted.
+// Layers with in_dim % 32 != 0 (the 2-, 3- and 12-wide first layers) take nn.Linear's layout on the vector units.
+constexpr int kR32 = 32;
+constexpr int kLdAct = kMaxDim + 4;   // row stride = 4 mod 64 floats: the 16 lanes of a ds_read_b128 phase hit 16 distinct 4-bank slots
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void mlp_chain_r32_kernel(simpb_mlp_args args) {
+  constexpr int kThreads = WAVES * 64;
+  constexpr bool kTwoTiles = WAVES == 4;   // 4 waves: two column tiles per wave; 8 waves: one
+  __shared__ float act[2][kR32][kLdAct];
+  const simpb_mlp_chain& ch = args.chain[blockIdx.y];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * kR32;
+  if (skip_dead_rows(args, args.chain[blockIdx.y], row0, kR32, threadIdx.x, kThreads)) return;
+  const int N = args.num_rows;
+
+  if (ch.in_mode == SIMPB_MLP_IN_SINE2D) {
+    for (int idx = tid; idx < kR32 * 256; idx += kThreads) {
+      const int r = idx >> 8, j = idx & 255;
+      const int row = row0 + r;
+      float v = 0.f;
+      if (row < N) {
+        const int axis = j < 128 ? 1 : 0, i = j & 127;
+        const float coord = ch.x[(size_t)row * ch.ldx + axis] * 6.283185307179586f;
+        const float dim_t = powf(10000.f, (float)(2 * (i >> 1)) / 128.f);
+        const float p = coord / dim_t;
+        v = (i & 1) ? cosf(p) : sinf(p);
+      }
+      act[0][r][j] = v;
+    }
+  } else if (ch.in_mode == SIMPB_MLP_IN_ROWS_LN) {
+    // the decoder's `norm` operator in front of this head (the 4-row kernel's arithmetic): one wave per row, eight rows each
+    const int D = ch.in_dim;
+    const int live = args.m_live ? min(N, *args.m_live) : N;
+    float g[kMaxDim / 64], be[kMaxDim / 64];
+#pragma unroll
+    for (int j = 0; j < kMaxDim / 64; ++j) {
+      const int e = lane + 64 * j;
+      g[j] = e < D ? ch.ln_w[e] : 0.f;
+      be[j] = e < D ? ch.ln_b[e] : 0.f;
+    }
+    for (int r = wave; r < kR32; r += WAVES) {
+      const int row = row0 + r;
+      const bool in_rows = row < N, alive = row < live;
+      float v[kMaxDim / 64], x2v[kMaxDim / 64];
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < kMaxDim / 64; ++j) {
+        const int e = lane + 64 * j;
+        const bool in = e < D;
+        v[j] = (in && in_rows) ? ch.x[(size_t)row * ch.ldx + e] : 0.f;
+        x2v[j] = (in && in_rows && ch.x2) ? ch.x2[(size_t)row * ch.ldx2 + e] : 0.f;
+        sum += v[j];
+      }
+      sum = wave_sum(sum);
+      const float mean = sum / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < kMaxDim / 64; ++j) {
+        const float d = (lane + 64 * j) < D ? v[j] - mean : 0.f;
+        q += d * d;
+      }
+      q = wave_sum(q);
+      const float inv = 1.f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+      for (int j = 0; j < kMaxDim / 64; ++j) {
+        const int e = lane + 64 * j;
+        if (e < D) {
+          const float y = alive ? (v[j] - mean) * inv * g[j] + be[j] : 0.f;
+          if (ch.ln_out && in_rows) ch.ln_out[(size_t)row * ch.ld_ln_out + e] = y;
+          act[0][r][e] = y + x2v[j];
+        }
+      }
+    }
+  } else {
+    for (int idx = tid; idx < kR32 * ch.in_dim; idx += kThreads) {
+      const int r = idx / ch.in_dim, k = idx - r * ch.in_dim;
+      const int row = row0 + r;
+      float v = 0.f;
+      if (row < N) {
+        v = ch.x[(size_t)row * ch.ldx + k];
+        if (ch.x2) v += ch.x2[(size_t)row * ch.ldx2 + k];
+      }
+      act[0][r][k] = v;
+    }
+  }
+  __syncthreads();
+
+  const int r32 = lane & 31, half = lane >> 5;
+  int cur = 0;
+  int width = ch.in_mode == SIMPB_MLP_IN_SINE2D ? 256 : ch.in_dim;
+  for (int o = 0; o < ch.n_ops; ++o) {
+    const simpb_mlp_op& op = ch.ops[o];
+    if (op.type == SIMPB_MLP_LINEAR) {
+      const int K = op.in_dim, D = op.out_dim;
+      if ((K & 31) == 0) {  // fragment-packed weights
+        const int ntile = (D + 31) >> 5, nchunk = K >> 5;
+        const int t0 = kTwoTiles ? 2 * wave : wave;
+        if (t0 < ntile) {
+          const bool two = kTwoTiles && t0 + 1 < ntile;     // wave-uniform
+          const int t1 = two ? t0 + 1 : t0;                 // (a lone last tile is loaded twice and multiplied once)
+          const f32x4* w0 = reinterpret_cast<const f32x4*>(op.w) + (size_t)t0 * nchunk * 256 + lane;
+          const f32x4* w1 = reinterpret_cast<const f32x4*>(op.w) + (size_t)t1 * nchunk * 256 + lane;
+          const float* ar = &act[cur][r32][16 * half];
+          f32x16 acc0, acc1;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+          f32x4 wa[2][4], wb[2][4];
+          auto fetch = [&](auto set_c, int chunk) __attribute__((always_inline)) {
+            constexpr int set = decltype(set_c)::value;
+            const int c = min(chunk, nchunk - 1);           // unconditional, clamped: past the end the last chunk again
+            static_for<0, 4>([&](auto q) __attribute__((always_inline)) {
+              constexpr int qq = decltype(q)::value;
+              wa[set][qq] = w0[(size_t)c * 256 + 64 * qq];
+              if constexpr (kTwoTiles) wb[set][qq] = w1[(size_t)c * 256 + 64 * qq];
+            });
+          };
+          auto work = [&](auto set_c, int chunk) __attribute__((always_inline)) {
+            constexpr int set = decltype(set_c)::value;
+            f32x4 a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(ar + 32 * chunk + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], wa[set][q][e], acc0, 0, 0, 0);
+            if (kTwoTiles && two) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], wb[set][q][e], acc1, 0, 0, 0);
+            }
+          };
+          fetch(std::integral_constant<int, 0>{}, 0);
+          for (int c = 0; c < nchunk; c += 2) {
+            fetch(std::integral_constant<int, 1>{}, c + 1);
+            work(std::integral_constant<int, 0>{}, c);
+            fetch(std::integral_constant<int, 0>{}, c + 2);
+            if (c + 1 < nchunk) work(std::integral_constant<int, 1>{}, c + 1);
+          }
+          // C/D of a 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * half
+          const int c0 = 32 * t0 + r32, c1 = 32 * t0 + 32 + r32;
+          const bool cv0 = c0 < D, cv1 = two && c1 < D;
+          const float bias0 = (op.b && cv0) ? op.b[c0] : 0.f, bias1 = (op.b && cv1) ? op.b[c1] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int rr = (i & 3) + 8 * (i >> 2) + 4 * half;
+            const float v0 = acc0[i] + bias0, v1 = acc1[i] + bias1;
+            if (cv0) act[cur ^ 1][rr][c0] = op.relu ? fmaxf(v0, 0.f) : v0;
+            if (cv1) act[cur ^ 1][rr][c1] = op.relu ? fmaxf(v1, 0.f) : v1;
+          }
+        }
+      } else if (tid < D) {  // K = 2, 3, 12: weights as stored, [D][K]; one thread per column
+        float acc[kR32];
+        const float b = op.b ? op.b[tid] : 0.f;
+#pragma unroll
+        for (int r = 0; r < kR32; ++r) acc[r] = b;
+        const float* wr = op.w + (size_t)tid * K;
+        for (int k = 0; k < K; ++k) {
+          const float wv = wr[k];
+#pragma unroll
+          for (int r = 0; r < kR32; ++r) acc[r] = fmaf(act[cur][r][k], wv, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < kR32; ++r) act[cur ^ 1][r][tid] = op.relu ? fmaxf(acc[r], 0.f) : acc[r];
+      }
+      __syncthreads();
+      cur ^= 1;
+      width = D;
+    } else {
+      // LayerNorm: one wave per row, 64 lanes x 4 elements, eight rows per wave
+      const int D = op.in_dim;
+      float g[kMaxDim / 64], be[kMaxDim / 64];
+#pragma unroll
+      for (int j = 0; j < kMaxDim / 64; ++j) {
+        const int e = lane + 64 * j;
+        g[j] = e < D ? op.w[e] : 0.f;
+        be[j] = e < D ? op.b[e] : 0.f;
+      }
+#pragma unroll 2
+      for (int r = wave; r < kR32; r += WAVES) {
+        float v[kMaxDim / 64];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxDim / 64; ++j) {
+          const int e = lane + 64 * j;
+          v[j] = e < D ? act[cur][r][e] : 0.f;
+          sum += v[j];
+        }
+        sum = wave_sum(sum);
+        const float mean = sum / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxDim / 64; ++j) {
+          const float d = (lane + 64 * j) < D ? v[j] - mean : 0.f;
+          q += d * d;
+        }
+        q = wave_sum(q);
+        const float inv = 1.f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < kMaxDim / 64; ++j) {
+          const int e = lane + 64 * j;
+          if (e < D) act[cur][r][e] = (v[j] - mean) * inv * g[j] + be[j];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int idx = tid; idx < kR32 * width; idx += kThreads) {
+    const int r = idx / width, t = idx - r * width;
+    const int row = row0 + r;
+    if (row < N) {
+      float v = act[cur][r][t];
+      if (ch.out_scale) v *= ch.out_scale[t];
+      if (ch.post) v = post_stage(ch, v, row, t);
+      ch.out[(size_t)row * ch.ldo + t] = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream) {
@@ -722,7 +955,7 @@ extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream)
       return SIMPB_EINVAL;
     if (ch.post == SIMPB_MLP_POST_REFINE3D && ch.div && ch.div_rows <= 0) return SIMPB_EINVAL;
     if (ch.in_mode == SIMPB_MLP_IN_SINE2D && ch.ldx < 2) return SIMPB_EINVAL;
-    if (ch.in_mode == SIMPB_MLP_IN_ROWS_LN && (args->weights_transposed != 2 || !ch.ln_w || !ch.ln_b ||
+    if (ch.in_mode == SIMPB_MLP_IN_ROWS_LN && ((args->weights_transposed != 2 && args->weights_transposed != 3) || !ch.ln_w || !ch.ln_b ||
                                                (ch.ln_out && ch.ld_ln_out < ch.in_dim)))
       return SIMPB_EINVAL;
     if (ch.in_mode < 0 || ch.in_mode > SIMPB_MLP_IN_ROWS_LN) return SIMPB_EINVAL;
@@ -739,7 +972,13 @@ extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream)
     }
   }
   (void)hipGetLastError();
-  if (args->weights_transposed == 2) {
+  if (args->weights_transposed == 3) {
+    // 32-row variant on the 32x32 matrix tiles (fragment-packed weights): launches with thousands of rows
+    dim3 grid((args->num_rows + kR32 - 1) / kR32, args->num_chains);
+    // (8 waves with one column tile each were measured too: refine2d 204 us against 147 us at 8.9 k rows -- every wave
+    // re-reads the A tile, and half the B registers in flight per wave)
+    hipLaunchKernelGGL(mlp_chain_r32_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), *args);
+  } else if (args->weights_transposed == 2) {
     // 4-row matrix-core variant (k4-packed weights): 4 rows x 4 waves
     dim3 grid((args->num_rows + kR4 - 1) / kR4, args->num_chains);
     hipLaunchKernelGGL(mlp_chain_r4_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), *args);

@@ -17,6 +17,10 @@ POST_NONE, POST_REFINE3D, POST_REFINE2D, POST_SIGMOID = 0, 1, 2, 3
 # routes.chain_rows4 (shipped): 4-row workgroups on the 4x4 matrix blocks, weights k4-packed [in/4][out][4]
 # (csrc/mlp_chain.hip: mlp_chain_r4_kernel): 225 workgroups for 900 rows instead of 57. Off: the 16-row matrix-core kernel
 # on the weights as stored, or (routes.chain_transposed) the VALU kernel on transposed copies.
+# Launches with at least WIDE_ROWS rows (a batch of camera streams: runner independent_streams) take the 32-row kernel on the
+# 32x32 matrix tiles (mlp_chain_r32_kernel, fragment-packed weights): at ~9 k rows the 4-row kernel sits at the issue rate of
+# its 4x4 matrix instruction, a quarter of the fp32 matrix rate.
+WIDE_ROWS = 4096
 LINEAR, LAYERNORM = 0, 1
 IN_ROWS, IN_SINE2D, IN_ROWS_LN = 0, 1, 2
 
@@ -94,13 +98,39 @@ class ChainPlan:
             self._wt[key] = hit
         return hit[1]
 
-    def fill(self, chain, keep):
+    def _fragments(self, lin):
+        """Wq[t][c][q][32 h + r][e] = W[32 t + r][32 c + 16 h + 4 q + e] (f32, zeros past out_dim): the B operand of
+        v_mfma_f32_32x32x2f32 for tile t and 32-deep chunk c as four coalesced 1-KiB wave loads (csrc/mlp_chain.hip)."""
+        key = ("frag", id(lin))
+        w = lin.weight
+        tag = (w.data_ptr(), w._version, w.device)
+        hit = self._wt.get(key)
+        if hit is None or hit[0] != tag:
+            n, k = w.shape
+            tiles = -(-n // 32)
+            full = torch.zeros(tiles * 32, k, device=w.device, dtype=torch.float32)
+            full[:n] = w.detach().float()
+            # [t, r, c, h, q, e] -> [t, c, q, h, r, e]
+            hit = (tag, full.reshape(tiles, 32, k // 32, 2, 4, 4).permute(0, 2, 4, 3, 1, 5).contiguous())
+            self._wt[key] = hit
+        return hit[1]
+
+    def fill(self, chain, keep, wide=False):
         chain.n_ops = len(self.ops)
         for j, (typ, din, dout, relu, m) in enumerate(self.ops):
             op = chain.ops[j]
             op.type, op.in_dim, op.out_dim, op.relu = typ, din, dout, relu
             if typ == LINEAR:
-                if routes.R.chain_rows4 and din % 4 == 0:
+                if wide and din % 32 == 0:
+                    wq = self._fragments(m)
+                    keep.append(wq)
+                    op.w = wq.data_ptr()
+                elif wide:
+                    w = m.weight
+                    if not w.is_contiguous() or w.dtype != torch.float32:
+                        raise ValueError("mlp_chain reads nn.Linear weights in place: contiguous f32 expected")
+                    op.w = w.data_ptr()
+                elif routes.R.chain_rows4 and din % 4 == 0:
                     wp = self._packed(m)
                     keep.append(wp)
                     op.w = wp.data_ptr()
@@ -152,7 +182,10 @@ def run_chains(jobs, num_rows, device, m_live=None):
     args = _Args()
     args.num_rows, args.num_chains = int(num_rows), len(jobs)
     args.m_live = m_live.data_ptr() if m_live is not None else None
-    args.weights_transposed = 2 if routes.R.chain_rows4 else (1 if routes.R.chain_transposed else 0)
+    # (not the sine chains: their prologue is transcendental work per element, which 32-row workgroups serialise in front
+    # of the matrix work -- 2D encoder at 8.9 k rows: 84 us against 64 us on the 4-row kernel)
+    wide = routes.R.chain_rows4 and int(num_rows) >= WIDE_ROWS and not any(j.get("sine") for j in jobs)
+    args.weights_transposed = 3 if wide else 2 if routes.R.chain_rows4 else (1 if routes.R.chain_transposed else 0)
     keep = []
     for c, job in enumerate(jobs):
         ch = args.chain[c]
@@ -188,7 +221,7 @@ def run_chains(jobs, num_rows, device, m_live=None):
             if post.get("div") is not None:
                 ch.div, ch.div_rows, ch.div_col0 = post["div"].data_ptr(), post["div_rows"], post["div_col0"]
                 keep.append(post["div"])
-        plan.fill(ch, keep)
+        plan.fill(ch, keep, wide)
         keep += [xt, ot]
     status = _lib.lib().simpb_mlp_chain_forward(ctypes.byref(args), _stream())
     _lib.check(status, "simpb_mlp_chain_forward")

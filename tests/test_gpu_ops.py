@@ -409,6 +409,68 @@ def test_mlp_chain_kernel_variants_agree():
             assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), name
 
 
+def test_mlp_chain_32_row_kernel_equals_the_4_row_kernel():
+    """Launches with thousands of rows (a batch of camera streams per launch) take mlp_chain_r32_kernel (32x32 matrix tiles,
+    fragment-packed weights); it must agree with the shipped 4-row kernel on the same rows -- 3D anchor encoder (2-/3-wide
+    first layers on the vector units, 128/32/32/64-wide branches = 4/1/1/2 column tiles), both refinement
+    heads with their post stages (11-, 10-, 4-wide last layers: one partly filled tile), the LayerNorm of the decoder's
+    `norm` operator inside the launch, capacity rows (m_live) as zeros, a row count that is no multiple of 32 -- and with
+    the PyTorch modules on the CPU."""
+    from simpb_amd.plugin import fused
+    from simpb_amd.plugin.detection2d import SparseBox2DEncoder, SparseBox2DRefinementModule
+    from simpb_amd.plugin.detection3d import SparseBox3DEncoder, SparseBox3DRefinementModule
+    n = 4171
+    torch.manual_seed(1)
+    enc = SparseBox3DEncoder(embed_dims=[128, 32, 32, 64], vel_dims=3, mode="cat", output_fc=False, in_loops=1, out_loops=4)
+    enc2 = SparseBox2DEncoder(embed_dims=256, with_sin_embed=True, in_loops=1, out_loops=2)
+    ref3 = SparseBox3DRefinementModule(embed_dims=256, num_cls=10, refine_yaw=True, with_quality_estimation=True)
+    ref2 = SparseBox2DRefinementModule(embed_dims=256, num_cls=10, with_alpha_branch=True)
+    norm = torch.nn.LayerNorm(256)
+    for seed, m in enumerate((enc, enc2, ref3, ref2, norm)):
+        synth.load_procedural(m, seed=11 + seed)
+    box, pts = torch.randn(1, n, 11), torch.rand(1, n, 2) * 1.2 - 0.1
+    f, e, a2 = torch.randn(1, n, 256), torch.randn(1, n, 256), torch.rand(1, n, 2)
+    dt = torch.tensor([0.5])
+    live = torch.tensor([3000], dtype=torch.int32, device="cuda")
+    with torch.no_grad():
+        want = dict(enc=torch.cat([enc.pos_fc(box[..., 0:3]), enc.size_fc(box[..., 3:6]), enc.yaw_fc(box[..., 6:8]),
+                                   enc.vel_fc(box[..., 8:11])], -1), enc2=enc2(pts), ref3=ref3(norm(f), box, e, dt, True),
+                    ref2=ref2(norm(f), a2, e))
+    mods = [m.cuda() for m in (enc, enc2, ref3, ref2, norm)]
+
+    def run():
+        with torch.no_grad():
+            out = dict(enc=enc(box.cuda()), enc2=enc2(pts.cuda(), m_live=live),
+                       ref3=ref3(f.cuda(), box.cuda(), e.cuda(), dt.cuda(), True, norm=norm),
+                       ref2=ref2(f.cuda(), a2.cuda(), e.cuda(), m_live=live, norm=norm))
+            out["norm3"], out["norm2"] = None, ref2.norm_out
+            return out
+
+    wide = run()
+    keep = fused.WIDE_ROWS
+    try:
+        fused.WIDE_ROWS = 1 << 30
+        narrow = run()
+    finally:
+        fused.WIDE_ROWS = keep
+
+    def leaves(x):
+        return [t for t in (x if isinstance(x, (tuple, list)) else [x]) if torch.is_tensor(t)]
+
+    for k in ("enc", "enc2", "ref3", "ref2", "norm2"):
+        rows = 3000 if k in ("enc2", "ref2", "norm2") else n   # (rows past m_live are capacity slots: zeros or whatever the tile computed)
+        for g_, w_ in zip(leaves(wide[k]), leaves(narrow[k])):
+            assert g_.shape == w_.shape
+            assert float((g_[:, :rows] - w_[:, :rows]).abs().max()) < 3e-5 * max(1.0, float(w_[:, :rows].abs().max())), k
+    for k in ("enc", "ref3"):
+        for g_, w_ in zip(leaves(wide[k]), leaves(want[k])):
+            assert float((g_.cpu() - w_).abs().max()) < 1e-4 * max(1.0, float(w_.abs().max())), k
+    for k in ("enc2", "ref2"):   # rows past m_live are capacity slots
+        for g_, w_ in zip(leaves(wide[k]), leaves(want[k])):
+            assert float((g_.cpu()[:, :3000] - w_[:, :3000]).abs().max()) < 1e-4 * max(1.0, float(w_.abs().max())), k
+    assert float(wide["enc2"][:, 3008:].abs().max()) == 0.0   # workgroups whose 32 rows are all capacity slots write zeros
+
+
 def test_aggregate_with_alpha_in_launch_equals_two_launches():
     """ReWeight.alpha folded into the 2D -> 3D aggregation launch (csrc/alloc.hip) against the row-dot launch followed by the
     aggregation on its output, and against the definition (aggregation.py:23-35) in float64."""
