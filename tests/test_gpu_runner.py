@@ -544,6 +544,40 @@ def test_batch_of_independent_streams_equals_one_runner_per_stream(bs, pipelined
                 raise AssertionError(f"stream {b}, frame {f}: {e}") from e
 
 
+def test_batch_of_independent_streams_overflow_reruns_and_matches_a_roomy_run():
+    """A stream that needs more 2D slots than the per-stream capacity sets the overflow flag (csrc/alloc.hip clips it like a
+    batch of one); the runner re-runs the frame with a larger slot array on the untouched bank, as for a single stream. The
+    flat layout packs live slots first, so the capacity changes no live slot's position: the detections must EQUAL those of
+    a run that had room from the start, bit for bit (same images, same batch, deterministic kernels)."""
+    from simpb_amd import configs, plugin
+    from simpb_amd.runner import PipelinedRunner
+    wh, bs, frames = (352, 128), 2, 6
+
+    def make():
+        cfg = configs.simpb_plus(anchor=synth.anchors(900))
+        model = plugin.build_detector(cfg["model"]).eval()
+        synth.load_procedural(model)
+        return model.cuda().fuse_conv_bn().half_backbone()
+
+    imgs = [synth.images(bs, f % 4, wh).cuda() for f in range(frames)]
+    metas = [synth.frame_metas(bs, f, wh) for f in range(frames)]
+    outs = {}
+    for cap in (256, 1536):
+        r = PipelinedRunner(make(), bs, (wh[1], wh[0]), capacity=cap, device=torch.device("cuda"), use_graph=True,
+                            independent_streams=True)
+        out = [r.step(imgs[f], metas[f]) for f in range(frames)]
+        outs[cap] = out[1:] + [r.flush()]
+        if cap == 256:
+            assert r.stats["overflow"] >= 1 and r.capacity > 256, (r.stats, r.capacity)
+        else:
+            assert r.stats["overflow"] == 0
+    for f in range(frames):
+        for b in range(bs):
+            a, c = outs[256][f][b]["img_bbox"], outs[1536][f][b]["img_bbox"]
+            for k in ("boxes_3d", "scores_3d", "labels_3d", "boxes_2d", "scores_2d", "labels_2d", "camidx_2d", "instance_ids"):
+                assert torch.equal(torch.as_tensor(np.asarray(a[k])), torch.as_tensor(np.asarray(c[k]))), (f, b, k)
+
+
 def _matched_fraction(got, want, tol):
     """Fraction of the rows of `want` that have a row of `got` within tol (max norm over the columns)."""
     got, want = (torch.as_tensor(np.asarray(x, np.float64)) for x in (got, want))
