@@ -23,7 +23,7 @@ def _oracle():
 
 def test_library_loaded():
     from simpb_amd import _lib
-    assert _lib.lib().simpb_abi_version() == 5
+    assert _lib.lib().simpb_abi_version() == 6
 
 
 def test_daf_golden_fallback_case():
