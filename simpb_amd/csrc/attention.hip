@@ -46,10 +46,13 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
   const bool q_ok = qg < Nq;
 
   int cam_q = 0, kb = 0, ke = Nk;
+  int my_lo = 0, my_hi = Nk;   // this lane's query attends keys [my_lo, my_hi): its own camera group (groups are contiguous slot ranges)
   if (GROUPED) {
     cam_q = q_ok ? query_cam[qg] : -1;
     int lo = cam_q >= 0 ? group_start[cam_q] : 0x7fffffff;
     int hi = cam_q >= 0 ? group_start[cam_q + 1] : 0;
+    my_lo = lo;
+    my_hi = hi;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
       lo = min(lo, __shfl_xor(lo, m));
@@ -96,22 +99,27 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
       kreg[4 * j + 0] = t.x; kreg[4 * j + 1] = t.y; kreg[4 * j + 2] = t.z; kreg[4 * j + 3] = t.w;
     }
   };
-  float kcur[32], knext[32];
-  const int kt0 = kb + 32 * wave;
-  if (kt0 < ke) load_k(kt0, kcur);
-  for (int kt = kt0; kt < ke; kt += 32 * kWaves) {
-    // V values of this tile: lane (d, half) holds V[key kt + acc_row(s, half)][d], s = 0..15
-    float va0[16], va1[16];
+  // V values of a tile: lane (d, half) holds V[key kt + acc_row(s, half)][d], s = 0..15
+  auto load_v = [&](int kt, float (&a0)[16], float (&a1)[16]) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int kidx = kt + acc_row(s, half);
       const float* vp = vbase + (size_t)(kidx < ke ? kidx : kb) * ldv + qi;  // past the range: weight 0 below
-      va0[s] = vp[0];
-      va1[s] = vp[32];
+      a0[s] = vp[0];
+      a1[s] = vp[32];
     }
+  };
+  float kcur[32], knext[32];
+  const int kt0 = kb + 32 * wave;
+  if (kt0 < ke) load_k(kt0, kcur);
+  for (int kt = kt0; kt < ke; kt += 32 * kWaves) {
+    float va0[16], va1[16];
+    load_v(kt, va0, va1);
     // requested UNCONDITIONALLY (past the last tile load_k clamps every row to the first key of the
     // range and the values are never used): a load behind `if (ktn < ke)` made the compiler wait for
-    // every outstanding load -- these and the V values above -- in front of the S^T product
+    // every outstanding load -- these and the V values above -- in front of the S^T product.
+    // (V of the NEXT tile requested here as well, a whole tile ahead, was measured slower: 35 vs 30 us at 900 x 900 --
+    // 248-256 VGPRs and the copies of 64 more registers per tile.)
     const int ktn = kt + 32 * kWaves;
     load_k(ktn, knext);
     __builtin_amdgcn_sched_barrier(0);  // the requests stay here, ahead of the matrix work (the scheduler sank them)
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
     for (int r = 0; r < 16; ++r) {
       const int kidx = kt + acc_row(r, half);
       bool ok = kidx < ke && q_ok;
-      if (GROUPED) ok = ok && cam_q >= 0 && query_cam[min(kidx, Nk - 1)] == cam_q;
+      if (GROUPED) ok = ok && kidx >= my_lo && kidx < my_hi;   // (= query_cam[kidx] == cam_q, without 16 loads per tile in front of the softmax)
       st[r] = ok ? st[r] : -INFINITY;
       mt = fmaxf(mt, st[r]);
     }
