@@ -118,8 +118,10 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f32_kernel(
     // requested UNCONDITIONALLY (past the last tile load_k clamps every row to the first key of the
     // range and the values are never used): a load behind `if (ktn < ke)` made the compiler wait for
     // every outstanding load -- these and the V values above -- in front of the S^T product.
-    // (V of the NEXT tile requested here as well, a whole tile ahead, was measured slower: 35 vs 30 us at 900 x 900 --
-    // 248-256 VGPRs and the copies of 64 more registers per tile.)
+    // (V of the NEXT tile requested a whole tile ahead was measured slower in both forms -- with K at the top: 35 vs 30 us
+    // at 900 x 900, 80 loads in flight against a counter of 63; behind the S^T product with two alternating register sets:
+    // 31.3 us, and 31-37 vs 25-31 us for the grouped form at 314 VGPRs. What is exposed per tile is not the V round trip but
+    // the ~300 vector instructions of the softmax, which one wave per SIMD cannot overlap with its own matrix work.)
     const int ktn = kt + 32 * kWaves;
     load_k(ktn, knext);
     __builtin_amdgcn_sched_barrier(0);  // the requests stay here, ahead of the matrix work (the scheduler sank them)
