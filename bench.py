@@ -403,7 +403,7 @@ def main():
         tokens = 6 * sum((args.image_wh[1] // s) * (args.image_wh[0] // s) for s in (4, 8, 16, 32))
 
         def roofline(k, what):
-            feat_mb = tokens * 256 * k.get("feature_bytes_per_element", 4) / 1e6
+            feat_mb = args.bs * tokens * 256 * k.get("feature_bytes_per_element", 4) / 1e6   # (a launch reads the maps of all its streams)
             in_cache = feat_mb * 1e6 < 256 * 2 ** 20
             ach = k["nbytes"] / k["secs"] / 1e9
             traffic, src, prof_us = pmc_traffic(k["kernel"])
@@ -421,7 +421,8 @@ def main():
                           f"launch stream in {k['launches']} instrumented launches right after the timed region; the feature "
                           f"set it reads is {feat_mb:.1f} MB and " + ("fits the 256 MiB Infinity Cache, so `achieved` is an on-die rate and can "
                           "exceed the HBM peak: hbm_side_* = PMC bytes beyond L2 (2*FETCH_SIZE + WRITE_SIZE) / the same time"
-                          if in_cache else "does not fit the 256 MiB Infinity Cache"))
+                          if in_cache else "does not fit the 256 MiB Infinity Cache; `achieved` counts every tap row as its own read "
+                          "(SURVEY.md 8d), and the four taps of a sample and neighbouring samples share L2 lines, so it can still exceed the HBM peak"))
             if "valid_triples" in k:
                 r["valid_triples"] = k["valid_triples"]
             return r
