@@ -975,7 +975,8 @@ extern "C" int simpb_mlp_chain_forward(const simpb_mlp_args* args, void* stream)
   if (args->weights_transposed == 3) {
     // 32-row variant on the 32x32 matrix tiles (fragment-packed weights): launches with thousands of rows
     dim3 grid((args->num_rows + kR32 - 1) / kR32, args->num_chains);
-    // (8 waves with one column tile each were measured too: refine2d 204 us against 147 us at 8.9 k rows -- every wave
+    // (four register sets = three chunks in flight ahead of the one multiplied: 152 vs 147 us for refine2d, no better;
+    // 8 waves with one column tile each were measured too: refine2d 204 us against 147 us at 8.9 k rows -- every wave
     // re-reads the A tile, and half the B registers in flight per wave)
     hipLaunchKernelGGL(mlp_chain_r32_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), *args);
   } else if (args->weights_transposed == 2) {

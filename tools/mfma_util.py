@@ -8,7 +8,7 @@ import sys
 NAMES = {"gemm_f32_kernel<64": "gemm_f32_kernel<64,4,64>", "gemm_f32_kernel<32, 2": "gemm_f32_kernel<32,2,128>",
          "gemm_f32_kernel<32, 4": "gemm_f32_kernel<32,4,64>", "attention_f32_kernel<false": "attention_f32_kernel<false>",
          "attention_f32_kernel<true": "attention_f32_kernel<true>", "mlp_chain_mfma": "mlp_chain_mfma_kernel",
-         "mlp_chain_r4": "mlp_chain_r4_kernel", "linear_f32_mfma": "linear_f32_mfma", "linear_f16x3": "linear_f16x3 (value_proj)",
+         "mlp_chain_r4": "mlp_chain_r4_kernel", "mlp_chain_r32": "mlp_chain_r32_kernel", "linear_f32_mfma": "linear_f32_mfma", "linear_f16x3": "linear_f16x3 (value_proj)",
          "conv1x1_f16": "conv1x1_f16", "conv_staged_kernel<96, 128": "conv_staged<96,128> (FPN 3x3)", "conv_staged_kernel<96, 64": "conv_staged<96,64> (layer1 3x3)",
          "conv_staged_kernel<128, 64": "conv_staged<128,64> (1x1, Cin >= 512)", "conv3x3_f16_kernel": "conv3x3 direct", "linear_h2": "linear_h2 (value_proj)", "stem_conv_pool": "stem_conv_pool (7x7 stem + pool)"}
 per = collections.defaultdict(dict)
