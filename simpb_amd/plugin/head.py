@@ -335,7 +335,9 @@ class SimPBHead(BaseModule):
             elif op == "allocation":
                 assert self.instance_status == "3d"
                 k = len(ref_pts2d_list)
-                ragged = self.independent_streams and cap is not None and batch_size > 1
+                if self.independent_streams and batch_size > 1 and cap is None:
+                    raise ValueError("independent_streams needs a static capacity (the flat slot array has a fixed size)")
+                ragged = self.independent_streams and batch_size > 1
                 anchor2d, ref_depth2d, ref_trans_mask, ref_trans_shape, _, _, ref_query_groups, _ = layer(
                     anchor, metas, dense=False, capacity=cap,
                     overflow_out=overflow[k:k + 1] if overflow is not None else None, independent=ragged)
