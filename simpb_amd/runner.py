@@ -22,6 +22,12 @@ import torch
 from .plugin.detection3d import SparseBox3DDecoder
 
 
+# Captures are taken in thread-local mode: with a process group initialised (one process per GPU, dist.py) the collective
+# backend's watchdog thread polls events in the background, and in the default global mode a call of that kind from ANY thread
+# invalidates a capture in progress. Everything a capture itself does happens on the capturing thread.
+CAPTURE_MODE = "thread_local"
+
+
 class FrameRunner:
     def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True, independent_streams=False):
         """independent_streams: the batch is a set of independent camera streams, each decoded exactly as a batch of one
@@ -134,7 +140,7 @@ class FrameRunner:
         if warm and self.use_graph and not force_eager and self.graph is None and self.warm_frames >= 1:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
                 self.outputs = self._frame(dmetas, aug)
         if warm and self.graph is not None and not force_eager:
             if self.rec_consumed is not None:
@@ -212,7 +218,7 @@ class PipelinedRunner(FrameRunner):
             if self.use_graph and not force_eager and self.bb_graph[slot] is None and self.bb_runs[slot] >= 1:
                 self.s_bb.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.s_bb):
+                with torch.cuda.graph(g, stream=self.s_bb, capture_error_mode=CAPTURE_MODE):
                     self.bb_out[slot] = self._features(slot)
                 self.bb_graph[slot] = g
                 self.head_graph[slot] = None  # a decoder graph bound to the old buffer is stale
@@ -251,7 +257,7 @@ class PipelinedRunner(FrameRunner):
             if graph_ok and self.head_graph[slot] is None and self.head_runs[slot] >= 1:
                 self.s_head.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.s_head):
+                with torch.cuda.graph(g, stream=self.s_head, capture_error_mode=CAPTURE_MODE):
                     self.head_out[slot] = self._decode(self.fm[slot], dmetas, aug)
                 self.head_graph[slot] = g
             if graph_ok and self.head_graph[slot] is not None:
@@ -502,9 +508,9 @@ class SplitPipelinedRunner(PipelinedRunner):
             self._stage_slot(slot, metas, prev, self.s_head)
             with torch.cuda.stream(self.s_head):
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, stream=self.s_head):
+                with torch.cuda.graph(ga, stream=self.s_head, capture_error_mode=CAPTURE_MODE):
                     gen = self._part_a(slot, dmetas)
-                with torch.cuda.graph(gb, stream=self.s_head, pool=ga.pool()):
+                with torch.cuda.graph(gb, stream=self.s_head, pool=ga.pool(), capture_error_mode=CAPTURE_MODE):
                     self.head_out[slot] = self._part_b(gen, aug)
                 del gen
             self.pre_graph[slot], self.head_graph[slot] = ga, gb
