@@ -141,9 +141,12 @@ class DetectionGather:
             at = 0
             for r in records2d:
                 n, rows = r.shape[:2]
-                if r.shape[2] != RECORD2D_WIDTH or rows > self.rows2d:
-                    raise ValueError(f"2D record {tuple(r.shape)} does not fit [*, <= {self.rows2d}, {RECORD2D_WIDTH}]")
-                self.send2d[at:at + n, :rows].copy_(r, non_blocking=True)   # (rows past it are pad rows and stay so: capacities only grow)
+                if r.shape[2] != RECORD2D_WIDTH:
+                    raise ValueError(f"2D record {tuple(r.shape)} is not [*, rows, {RECORD2D_WIDTH}]")
+                # a runner's slot array may be LONGER than the exchange capacity (capacities are rounded up to 128: 5 504 for
+                # 900 x 6), never its live part: live slots come first and there are at most num_anchor x num_cams of them
+                rows = min(rows, self.rows2d)
+                self.send2d[at:at + n, :rows].copy_(r[:, :rows], non_blocking=True)   # (rows past it are pad rows and stay so: capacities only grow)
                 at += n
             if at != self.send.shape[0]:
                 raise ValueError(f"{at} 2D stream records submitted, {self.send.shape[0]} expected")

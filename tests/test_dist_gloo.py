@@ -155,3 +155,23 @@ def test_detection_gather_world2_drives_the_bench_exchange():
                 assert torch.equal(got2d["boxes_2d"], rec[keep, :4]) and torch.equal(got2d["camidx_2d"], rec[keep, 7])
         ids = unpack_detections(torch.from_numpy(got[0][1][which].view("float32")))["instance_ids"]
         assert int(ids[1, 0, 1]) == 1 + 300 * frame + (1 << 25) * 3 and int(ids[0, 0, 0]) == -1
+
+
+def test_detection_gather_takes_a_slot_array_longer_than_the_exchange_capacity():
+    """A runner's capacity is rounded up to a multiple of 128 (5 504 slots for 900 anchors x 6 cameras) while the exchange
+    carries num_anchor x num_cams = 5 400 rows: live slots come first and can never exceed that, so the surplus rows are pad
+    rows and are simply not sent (world 1, CPU)."""
+    from simpb_amd.dist import DetectionGather, unpack_detections2d
+    rows2d = 24
+    g = DetectionGather(2, 300, torch.device("cpu"), rows2d=rows2d)
+    rec3d = torch.randn(2, 300, 15)
+    rec2d = torch.zeros(2, rows2d + 8, 8)
+    rec2d[..., 6:8] = -1.0
+    rec2d[0, :5, :6] = torch.randn(5, 6)
+    rec2d[0, :5, 6] = torch.arange(5.0)
+    rec2d[0, :5, 7] = 2.0
+    g.submit([rec3d], records2d=[rec2d])
+    out = g.result2d()
+    assert tuple(out.shape) == (1, 2, rows2d, 8) and torch.equal(out[0], rec2d[:, :rows2d])
+    got = unpack_detections2d(out[0])
+    assert len(got[0]["boxes_2d"]) == 5 and len(got[1]["boxes_2d"]) == 0
