@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--meter-frames", type=int, default=8, help="instrumented eager frames for the roofline leg")
     ap.add_argument("--no-conv-search", action="store_true",
                     help="do not let MIOpen benchmark convolution algorithms during warm-up (cudnn.benchmark off)")
+    ap.add_argument("--route", action="append", default=[], metavar="NAME=0|1",
+                    help="measurement only: take the other branch of a route switch (simpb_amd/plugin/routes.py) for this run")
     ap.add_argument("--reference-batch", action="store_true",
                     help="with --bs > 1: the reference's batch semantics (camera groups padded to the max over the batch, "
                          "allocation.py:91-99) instead of bs independent streams decoded as batches of one")
@@ -455,4 +457,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    _routes = [a for i, a in enumerate(sys.argv) if i and sys.argv[i - 1] == "--route"]
+    if _routes:   # (measurement only: the switches are read-only outside this context manager)
+        from simpb_amd.plugin import routes
+        with routes.override(**{k: bool(int(v)) for k, v in (r.split("=") for r in _routes)}):
+            main()
+    else:
+        main()

@@ -284,6 +284,16 @@ int simpb_conv3x3_nhwc_f16(void* y, float* tokens, void* tokens_f16, int tokens_
                            const void* weight, const void* bias, int num_images, int in_h, int in_w, int in_channels,
                            int out_channels, int stride, int relu, int variant, void* stream);
 
+/* The same 3x3 / stride 1 convolution for up to four inputs of one channel count in ONE launch, each result written as its
+ * level's token rows (f32 `tokens`, and f16 `tokens_f16` or NULL) exactly as simpb_conv3x3_nhwc_f16 does with `tokens`:
+ * the four `fpn_convs[i].conv` of mmdet's FPN (projects/configs/simpb_nus_r50_img_704x256.py:92-99) behind
+ * feature_maps_format (ops/__init__.py:63-92). x[j] f16 NHWC [num_images, in_h[j], in_w[j], Cin]; weight[j] f16
+ * [Cout, 3, 3, Cin]; bias[j] f16 [Cout]; level_start[j] = the level's first row inside a camera's tokens_per_cam rows.
+ * 96 x 128 staged tiles for every level (tiling 8 above): the small levels' tiles fill the last round of the large one. */
+int simpb_conv3x3_group_tokens_f16(int num_levels, float* tokens, void* tokens_f16, int tokens_per_cam, const int* level_start,
+                                   const void* const* x, const void* const* weight, const void* const* bias, int num_images,
+                                   const int* in_h, const int* in_w, int in_channels, int out_channels, int relu, void* stream);
+
 /* Attention core of torch.nn.MultiheadAttention (between in_proj and out_proj), exact fp32, flash
  * style, head_dim = 64: out[b,q,h*64+d] = sum_k softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,d].
  * q/k/v/out are [batch, N, heads*64] with row strides ldq/ldk/ldv/ldo (floats; batches are N*ld apart),

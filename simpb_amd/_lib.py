@@ -31,6 +31,7 @@ SIGNATURES = {
     "simpb_bias_relu_maxpool_nhwc_f16": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "simpb_conv1x1_nhwc_f16": ([_P] * 5 + [_I] * 8 + [_P, _I, _P], _I),
     "simpb_conv3x3_nhwc_f16": ([_P, _P, _P, _I, _I, _P, _P, _P] + [_I] * 8 + [_P], _I),
+    "simpb_conv3x3_group_tokens_f16": ([_I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P], _I),
     "simpb_stem_conv7x7_pool_f16": ([_P] * 4 + [_I] * 4 + [_P], _I),
     "simpb_image_to_nhwc4_f16": ([_P, _P] + [ctypes.c_longlong] * 4 + [_I] * 4 + [_P], _I),
     "simpb_linear_f16in_split": ([_P] * 5 + [_I] * 3 + [_P], _I),

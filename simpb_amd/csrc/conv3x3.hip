@@ -362,7 +362,7 @@ void launch(ConvArgs& a, hipStream_t stream) {
 // at a 144-byte row pitch). BMt x BNt output tile, WGM x WGN waves, each (BMt / WGM) x (BNt / WGN). The tile is chosen per shape so
 // that the grid fills whole rounds of the chip: 67 584 pixels are 528 tiles of 128 (two per CU and sixteen left over) but 704 of 96.
 template <int BMt, int BNt, int WGM, int WGN, int TAPS>
-__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 3 ? 3 : 2) void conv_staged_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_staged_tile(const ConvArgs& a, const int tile) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int AF = BMt / WGM / 32, NF = BNt / WGN / 32;
   static_assert(AF * WGM * 32 == BMt && NF * WGN * 32 == BNt && NF <= 2, "tile = waves x 32-row / 32-column fragments");
@@ -374,8 +374,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 3 ? 3 : 2) void conv_s
   _Float16* s_ab = reinterpret_cast<_Float16*>(smem);
   float* s_c = reinterpret_cast<float*>(smem);
 
-  const int tile = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= a.per_xcd || tile >= a.gx * a.gy) return;
   const int tx = tile / a.gy, ty = tile - tx * a.gy;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -526,6 +524,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 3 ? 3 : 2) void conv_s
 }
 
 template <int BMt, int BNt, int WGM, int WGN, int TAPS>
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 3 ? 3 : 2) void conv_staged_kernel(const ConvArgs a) {
+  // each XCD (blockIdx % 8) walks a contiguous range of tiles
+  const int tile = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= a.per_xcd || tile >= a.gx * a.gy) return;
+  conv_staged_tile<BMt, BNt, WGM, WGN, TAPS>(a, tile);
+}
+
+// Several convolutions of one tile shape in ONE launch (the FPN's four output convolutions: 240 us as four launches, of which
+// the three small levels -- 352, 88 and 22 tiles -- leave most of the chip idle for 97 us; in one launch their tiles fill
+// the last round of the large level's 1 408). Problem j owns the tiles [start[j], start[j + 1]) of one XCD-contiguous walk.
+constexpr int kMaxConvGroup = 4;
+struct ConvGroup {
+  ConvArgs a[kMaxConvGroup];
+  int start[kMaxConvGroup + 1];
+  int n, per_xcd;
+};
+template <int BMt, int BNt, int WGM, int WGN, int TAPS>
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 3 ? 3 : 2) void conv_staged_group_kernel(const ConvGroup g) {
+  const int gt = (blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= g.per_xcd || gt >= g.start[g.n]) return;
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < kMaxConvGroup; ++t)
+    if (t < g.n && gt >= g.start[t]) j = t;
+  conv_staged_tile<BMt, BNt, WGM, WGN, TAPS>(g.a[j], gt - g.start[j]);
+}
+
+template <int BMt, int BNt, int WGM, int WGN, int TAPS>
 void launch_staged(ConvArgs& a, hipStream_t stream) {
   a.gx = (a.P_out + BMt - 1) / BMt;
   a.gy = (a.Cout + BNt - 1) / BNt;
@@ -580,6 +606,47 @@ extern "C" int simpb_conv3x3_nhwc_f16(void* y, float* tokens, void* tokens_f16, 
     case 7: launch_staged<96, 64, 3, 1, 9>(a, s); break;     // 96 x 64, three waves: 704 workgroups for 67 584 pixels
     default: launch_staged<96, 128, 1, 4, 9>(a, s); break;   // 96 x 128, waves side by side along the channels
   }
+  return simpb_check_launch();
+}
+
+// The FPN's output convolutions (3x3, stride 1, Cin -> Cout, bias, no ReLU; mmdet FPN `fpn_convs[i].conv` after
+// tools/fuse_conv_bn.py:10-48) of up to four levels in ONE launch, each writing its level's token rows (f32 and, optionally,
+// f16) as simpb_conv3x3_nhwc_f16 does with `tokens`: x[j] f16 NHWC [num_images, in_h[j], in_w[j], Cin], weight[j] f16
+// [Cout, 3, 3, Cin], bias[j] f16 [Cout], level_start[j] the level's first row inside a camera's tokens_per_cam rows.
+extern "C" int simpb_conv3x3_group_tokens_f16(int num_levels, float* tokens, void* tokens_f16, int tokens_per_cam,
+                                              const int* level_start, const void* const* x, const void* const* weight,
+                                              const void* const* bias, int num_images, const int* in_h, const int* in_w,
+                                              int in_channels, int out_channels, int relu, void* stream) {
+  if (num_levels < 1 || num_levels > kMaxConvGroup || !tokens || !level_start || !x || !weight || !bias || !in_h || !in_w ||
+      num_images <= 0 || in_channels <= 0 || out_channels <= 0 || in_channels % BK != 0 || out_channels % 8 != 0 ||
+      ((reinterpret_cast<size_t>(tokens) | reinterpret_cast<size_t>(tokens_f16)) & 15))
+    return SIMPB_EINVAL;
+  ConvGroup g{};
+  long long total = 0;
+  for (int j = 0; j < num_levels; ++j) {
+    if (!x[j] || !weight[j] || !bias[j] || in_h[j] <= 0 || in_w[j] <= 0 ||
+        ((reinterpret_cast<size_t>(x[j]) | reinterpret_cast<size_t>(weight[j]) | reinterpret_cast<size_t>(bias[j])) & 15))
+      return SIMPB_EINVAL;
+    const long long p_out = (long long)num_images * in_h[j] * in_w[j];
+    if (p_out > (1ll << 30) || p_out * in_channels > (1ll << 31) - 1) return SIMPB_EINVAL;   // tap offsets are 32-bit
+    if (tokens_per_cam < in_h[j] * in_w[j] || level_start[j] < 0 || level_start[j] + in_h[j] * in_w[j] > tokens_per_cam)
+      return SIMPB_EINVAL;
+    g.a[j] = ConvArgs{nullptr, tokens, static_cast<_Float16*>(tokens_f16), static_cast<const _Float16*>(x[j]),
+                      static_cast<const _Float16*>(weight[j]), static_cast<const _Float16*>(bias[j]), nullptr, 0, (int)p_out,
+                      in_channels, out_channels, relu, 1, in_h[j], in_w[j], in_h[j], in_w[j], tokens_per_cam, level_start[j],
+                      0, 0, 0};
+    g.a[j].gx = (int)((p_out + 95) / 96);
+    g.a[j].gy = (out_channels + 127) / 128;
+    g.start[j] = (int)total;
+    total += (long long)g.a[j].gx * g.a[j].gy;
+  }
+  if (total > (1 << 24)) return SIMPB_EINVAL;
+  for (int j = num_levels; j <= kMaxConvGroup; ++j) g.start[j] = (int)total;
+  g.n = num_levels;
+  g.per_xcd = (int)((total + 7) / 8);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((conv_staged_group_kernel<96, 128, 1, 4, 9>), dim3((unsigned)(g.per_xcd * 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g);
   return simpb_check_launch();
 }
 

@@ -222,11 +222,17 @@ class FPN(BaseModule):
                 col = torch.empty(bs, num_cams * per_cam, cout, device=x0.device, dtype=torch.float32)
                 # the same rows without the widening: value_proj (group_attn.py:176) reads these (two-pass split product)
                 col16 = torch.empty(bs, num_cams * per_cam, cout, device=x0.device, dtype=torch.float16)
-                start = 0
-                for i in range(n):
-                    conv = self.fpn_convs[i].conv
-                    conv3x3_nhwc(laterals[i], conv.weight, conv.bias, relu=False, tokens=(col, per_cam, start, col16))
-                    start += shapes[i][0] * shapes[i][1]
+                starts = [sum(h * w for h, w in shapes[:i]) for i in range(n)]
+                if (routes.R.fpn_grouped_out and 1 < n <= 4 and len({m.conv.in_channels for m in self.fpn_convs}) == 1
+                        and len({m.conv.out_channels for m in self.fpn_convs}) == 1):
+                    # one launch for the four levels: the small levels' tiles fill the last round of the large one
+                    from .ops import conv3x3_group_tokens
+                    conv3x3_group_tokens(laterals, [m.conv.weight for m in self.fpn_convs], [m.conv.bias for m in self.fpn_convs],
+                                         col, per_cam, starts, col16)
+                else:
+                    for i in range(n):
+                        conv = self.fpn_convs[i].conv
+                        conv3x3_nhwc(laterals[i], conv.weight, conv.bias, relu=False, tokens=(col, per_cam, starts[i], col16))
                 col.simpb_f16 = col16
                 self.deferred_output_bias = False
                 self.wrote_tokens = [col, *token_tables(shapes, num_cams, col.device)]

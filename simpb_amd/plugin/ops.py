@@ -510,6 +510,35 @@ def conv3x3_nhwc(x, weight, bias, relu=True, stride=1, tokens=None, variant=0):
     return y
 
 
+def conv3x3_group_tokens(xs, weights, biases, col, per_cam, starts, col16=None, relu=False):
+    """conv3x3_nhwc(..., tokens=...) of up to four levels in ONE launch (csrc/conv3x3.hip: conv_staged_group_kernel): the
+    FPN's output convolutions. xs: channels_last f16 [N, Cin, H_j, W_j]; weights f16 [Cout, Cin, 3, 3]; biases f16 [Cout];
+    col f32 [bs, cams * per_cam, Cout] (and col16, the same rows in f16); starts[j] = level j's first row inside a camera."""
+    import ctypes
+    _require_gpu(*xs, *weights, *biases, col)
+    n, cin = xs[0].shape[:2]
+    cout = weights[0].shape[0]
+    k = len(xs)
+    if not (1 <= k <= 4 and len(weights) == k and len(biases) == k and len(starts) == k):
+        raise ValueError("conv3x3_group_tokens: 1..4 levels, one weight / bias / start each")
+    ws = []
+    for x, w, b in zip(xs, weights, biases):
+        if (x.dtype != torch.float16 or not x.is_contiguous(memory_format=torch.channels_last) or x.shape[0] != n or x.shape[1] != cin
+                or w.dtype != torch.float16 or tuple(w.shape) != (cout, cin, 3, 3) or b.dtype != torch.float16 or b.numel() != cout
+                or not b.is_contiguous() or cin % 64 or cout % 8):
+            raise ValueError("conv3x3_group_tokens takes channels_last f16 inputs of one channel count, f16 [Cout, Cin, 3, 3] weights")
+        ws.append(w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last))
+    if (col.dtype != torch.float32 or not col.is_contiguous() or col.shape[-1] != cout or col.numel() != n * per_cam * cout
+            or (col16 is not None and (col16.dtype != torch.float16 or not col16.is_contiguous() or col16.shape != col.shape))):
+        raise ValueError("conv3x3_group_tokens: col = contiguous f32 [bs, cams * tokens_per_cam, Cout] with bs * cams == N")
+    arr_p, arr_i = ctypes.c_void_p * k, ctypes.c_int * k
+    status = _lib.lib().simpb_conv3x3_group_tokens_f16(
+        k, _ptr(col), _ptr(col16) if col16 is not None else None, int(per_cam), arr_i(*[int(v) for v in starts]),
+        arr_p(*[x.data_ptr() for x in xs]), arr_p(*[w.data_ptr() for w in ws]), arr_p(*[b.data_ptr() for b in biases]), n,
+        arr_i(*[x.shape[2] for x in xs]), arr_i(*[x.shape[3] for x in xs]), cin, cout, 1 if relu else 0, _stream())
+    _lib.check(status, "simpb_conv3x3_group_tokens_f16")
+
+
 def _stem_weight_packed(weight):
     """f16 [28][2][64][4] fragment order of csrc/stem.hip from the stem's [64, 3, 7, 7] weight, cached on the tensor."""
     tag = (weight.data_ptr(), weight._version, str(weight.device))

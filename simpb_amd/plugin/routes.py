@@ -39,6 +39,9 @@ DEFAULTS = dict(
     stem_epilogue_kernel=True,
     # own 7x7 / stride-2 stem convolution (csrc/stem.hip). False: the vendor convolution.
     stem_kernel=True,
+    # the FPN's four output convolutions as ONE launch (conv_staged_group_kernel): the three small levels' tiles fill the last
+    # round of the large level's instead of three nearly empty launches of their own. False: one launch per level.
+    fpn_grouped_out=True,
     # static-capacity allocation as one three-kernel entry point. False: the stepwise entry points.
     alloc_static_fused=True,
     # QueryGroupMultiScaleDeformableAttention without value_proj over the 89 760 camera tokens: sample the raw tokens per

@@ -732,6 +732,35 @@ def test_conv3x3_writes_tokens():
 
 
 @gpu
+@pytest.mark.parametrize("shapes,images", [([(64, 176), (32, 88), (16, 44), (8, 22)], 6), ([(16, 44), (8, 22), (4, 11), (2, 6)], 12),
+                                           ([(5, 7), (3, 3)], 2)])
+def test_conv3x3_group_writes_the_tokens_of_every_level_in_one_launch(shapes, images):
+    """The FPN's four output convolutions as ONE launch (simpb_conv3x3_group_tokens_f16): the same 96 x 128 staged tiles as
+    tiling 8 of the single call, so every level's rows must EQUAL those the per-level calls with variant 8 write, f32 and
+    f16, at the shipped R50 map sizes, at small ones and with ragged tiles; rows of no level stay untouched."""
+    from simpb_amd.plugin.ops import conv3x3_group_tokens, conv3x3_nhwc
+    g = torch.Generator().manual_seed(len(shapes) * 7 + images)
+    c = 256
+    per_cam = sum(h * w for h, w in shapes) + 3          # (three spare rows per camera: nobody's)
+    starts = [sum(h * w for h, w in shapes[:i]) for i in range(len(shapes))]
+    xs = [torch.randn(images, c, h, w, generator=g).half().cuda().contiguous(memory_format=torch.channels_last) for h, w in shapes]
+    ws = [(torch.randn(c, c, 3, 3, generator=g) / 48).half().cuda().contiguous(memory_format=torch.channels_last) for _ in shapes]
+    bs_ = [torch.randn(c, generator=g).half().cuda() for _ in shapes]
+    want = torch.full((1, images * per_cam, c), -7.0, device="cuda")
+    want16 = torch.full((1, images * per_cam, c), -7.0, device="cuda", dtype=torch.float16)
+    for x, w, b, st in zip(xs, ws, bs_, starts):
+        conv3x3_nhwc(x, w, b, relu=False, tokens=(want, per_cam, st, want16), variant=8)
+    got, got16 = torch.full_like(want, -7.0), torch.full_like(want16, -7.0)
+    conv3x3_group_tokens(xs, ws, bs_, got, per_cam, starts, got16)
+    assert torch.equal(got, want) and torch.equal(got16, want16)
+    assert float(got.view(images, per_cam, c)[:, per_cam - 3:].max()) == -7.0
+    ref = F.conv2d(xs[-1].float(), ws[-1].float(), bs_[-1].float(), padding=1)          # and one level against fp32
+    h, w = shapes[-1]
+    rows = got.view(images, per_cam, c)[:, starts[-1]: starts[-1] + h * w].reshape(images, h, w, c).permute(0, 3, 1, 2)
+    assert float((rows - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
+
+
+@gpu
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("cin,cout,h,w", [(512, 256, 32, 88), (256, 256, 64, 176), (1024, 256, 16, 44), (192, 40, 6, 10)])
 def test_conv1x1_with_upsampled_residual(cin, cout, h, w, variant):
