@@ -460,31 +460,17 @@ def _check_against_replay(head, seen, out, metas, wh, name):
         assert rows_match_t(a["boxes_3d"], b["boxes_3d"], 1e-3), (name, f)
 
 
-def _as_golden(res, prefix):
-    """One decode_with2d dict in the key layout compare_result reads a golden from."""
-    t = res["trans_matrix"]
-    t = t.detach().cpu() if torch.is_tensor(t) else torch.as_tensor(t)
-    g = {prefix + k: np.asarray(res[k].detach().cpu() if torch.is_tensor(res[k]) else res[k])
-         for k in ("boxes_3d", "scores_3d", "cls_scores", "labels_3d", "boxes_2d", "scores_2d", "labels_2d", "camidx_2d",
-                   "instance_ids")}
-    g[prefix + "trans_shape"] = np.asarray(t.shape)
-    g[prefix + "trans_nz"] = torch.nonzero(t).numpy()
-    g[prefix + "query_groups"] = np.asarray(res["query_groups"], np.int64)
-    return g
-
-
-@pytest.mark.parametrize("bs,pipelined", [(3, True), (3, False)])
-def test_batch_of_independent_streams_equals_one_runner_per_stream(bs, pipelined):
+@pytest.mark.parametrize("bs", [3])
+def test_pipelined_batch_of_independent_streams_equals_the_plain_eager_batch(bs):
     """BASELINE config #3 in its throughput form ('keep per-sample counts in the native path'): bs camera
     streams with different headings and time origins through ONE runner launch per frame (independent_streams=True: one
-    flat 2D slot array over bs x 6 camera groups, csrc/alloc.hip alloc_scatter_ragged_kernel) must return, stream by
-    stream, what a runner of batch one returns for that stream -- images through the real backbone, eight frames with the
-    temporal bank, one stream jumping in time (the bank's max_time_interval mask). The fp16 backbone picks its tiles by
-    batch size and is not bit-identical between a batch and a batch of one, so (as in
-    test_pipelined_equals_plain_runner_with_real_backbone) the features are recorded as the batched decoder saw them and
-    stream b's slice is served to a plain eager runner of batch one. Compared like a golden: detections as sets within
-    1e-3, the 2D<->3D association as a relation, track ids up to a relabelling (fresh ids are numbered over the batch,
-    instance_bank.py:179-181)."""
+    flat 2D slot array over bs x 6 camera groups, csrc/alloc.hip alloc_scatter_ragged_kernel), images through the real
+    backbone, eight frames with the temporal bank, one stream jumping in time. The pipelined runner (two streams, replayed
+    graphs, backbone(t+1) beside decoder(t)) must return EXACTLY what the plain eager runner of the same batch returns for
+    the features the pipelined decoder saw (recorded and served again, as in
+    test_pipelined_equals_plain_runner_with_real_backbone): same kernels, same layout, so bit for bit -- a stale slot, a
+    decoder ahead of its backbone or a graph replayed on the wrong tables would show. That the batch equals one runner PER
+    STREAM is the next test's claim (it cannot be made bit for bit: the flat layout shifts the attention key tiles)."""
     from simpb_amd import configs, plugin
     from simpb_amd.runner import FrameRunner, PipelinedRunner
     wh = (352, 128)
@@ -498,50 +484,31 @@ def test_batch_of_independent_streams_equals_one_runner_per_stream(bs, pipelined
     frames = 8
     imgs = [synth.images(bs, f % 4, wh).cuda() for f in range(frames)]
     metas = [synth.frame_metas(bs, f, wh, jump=(1, 5, 10.0)) for f in range(frames)]
-
-    def one(m, b):
-        return dict(projection_mat=m["projection_mat"][b:b + 1], image_wh=m["image_wh"][b:b + 1],
-                    timestamp=m["timestamp"][b:b + 1], img_metas=[m["img_metas"][b]])
-
-    def snapshot(fm):
-        return [t.clone() for t in list(fm)[:3]]
-
-    kw = dict(capacity=1536, device=torch.device("cuda"), use_graph=True)
-    model = make()
+    batch = PipelinedRunner(make(), bs, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=True,
+                            independent_streams=True)
     seen, got = [], []
-    if pipelined:
-        batch = PipelinedRunner(model, bs, (wh[1], wh[0]), independent_streams=True, **kw)
-        for f in range(frames):
-            got.append(batch.step(imgs[f], metas[f]))
-            batch.s_bb.synchronize()
-            if f >= 1:
-                seen.append(snapshot(batch.fm[(f - 1) % 2]))
-        seen.append(snapshot(batch.fm[(frames - 1) % 2]))
-        got = got[1:] + [batch.flush()]
-    else:
-        batch = FrameRunner(model, bs, (wh[1], wh[0]), independent_streams=True, **kw)
-        inner, last = model.extract_feat, {}
-
-        def spy(img):
-            last["fm"] = inner(img)
-            return last["fm"]
-
-        model.extract_feat = spy
-        for f in range(frames):
-            got.append(batch.step(imgs[f], metas[f]))
-            seen.append(snapshot(last["fm"]))
+    for f in range(frames):
+        got.append(batch.step(imgs[f], metas[f]))
+        batch.s_bb.synchronize()
+        if f >= 1:
+            seen.append([t.clone() for t in list(batch.fm[(f - 1) % 2])[:3]])
+    seen.append([t.clone() for t in list(batch.fm[(frames - 1) % 2])[:3]])
+    got = got[1:] + [batch.flush()]
     assert batch.stats["replay"] >= 2 and batch.stats["overflow"] == 0, batch.stats
     assert tuple(batch.last_rec2d.shape) == (bs, 1536, 8) and tuple(batch.last_rec3d.shape) == (bs, 300, 15)
-    for b in range(bs):
-        replay = _ReplayModel(make().head)
-        plain = FrameRunner(replay, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=False)
-        for f in range(frames):
-            replay.load([seen[f][0][b:b + 1], seen[f][1], seen[f][2]])
-            want = plain.step(plain.img, one(metas[f], b))[0]["img_bbox"]
-            try:
-                compare_result(got[f][b]["img_bbox"], _as_golden(want, "w."), "w.")
-            except AssertionError as e:
-                raise AssertionError(f"stream {b}, frame {f}: {e}") from e
+    replay = _ReplayModel(make().head)
+    plain = FrameRunner(replay, bs, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=False,
+                        independent_streams=True)
+    for f in range(frames):
+        replay.load(seen[f])
+        want = plain.step(plain.img, metas[f])
+        for b in range(bs):
+            x, y = got[f][b]["img_bbox"], want[b]["img_bbox"]
+            assert set(x) == set(y)
+            for k in ("boxes_3d", "scores_3d", "labels_3d", "cls_scores", "instance_ids", "boxes_2d", "scores_2d", "labels_2d",
+                      "camidx_2d", "trans_matrix"):
+                assert torch.equal(torch.as_tensor(np.asarray(x[k])), torch.as_tensor(np.asarray(y[k]))), (f, b, k)
+            assert x["query_groups"] == y["query_groups"]
 
 
 def test_batch_of_independent_streams_overflow_reruns_and_matches_a_roomy_run():
@@ -587,13 +554,15 @@ def _matched_fraction(got, want, tol):
 
 
 def test_batch_of_independent_streams_frame_by_frame_from_the_same_state():
-    """The same claim as above at bs = 4, one stream jumping in time, checked frame by frame FROM THE SAME STATE: before
+    """A batch of independent streams must return, stream by stream, what a runner of batch one returns for that stream:
+    bs = 4, one stream jumping in time, checked frame by frame FROM THE SAME STATE: before
     frame f the plain batch-of-one runner of stream b is handed the bank state (cached features / anchors / confidences /
     track ids) the batched runner held for that stream, so a difference can only come from this frame's arithmetic.
     Why not the whole stream: with random weights the decoder is chaotic -- the flat layout shifts the attention key tiles
     of every stream but the first, results move by ~1e-5, and now and then that flips a top-k tie or an inside/outside
     test of the allocation, after which a few instances differ by 1e-2 and the difference spreads through the bank
-    (tools/diag_ragged.py: bs = 4, stream 1 from frame 3 on; none at bs = 3, above). Criteria per (stream, frame): same
+    (tools/diag_ragged.py: bs = 4, stream 1 from frame 3 on; at bs = 3 a whole-stream comparison held for 8 frames until an
+    unrelated change of the FPN's tiling moved the features by an fp16 ulp, then stream 1 flipped at its jump frame). Criteria per (stream, frame): same
     number of 3D rows, >= 97 % of the 3D rows (box, score, label) and >= 95 % of the 2D rows with a partner within
     1e-3 (2D boxes in pixels: 0.1); and all rows in at least 85 % of the (stream, frame) pairs."""
     from simpb_amd import configs, plugin
