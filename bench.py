@@ -29,7 +29,8 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node, one rank each (default: WORLD_SIZE under a launcher, otherwise 1)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--prime", type=int, default=10,
@@ -256,7 +257,9 @@ def launch_ranks(args):
     BEFORE this process has touched the GPU, and exit with its status. The child's rank 0 prints the JSON line."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    # device_count() may or may not create a HIP context on ROCm (it can fall back to hipGetDeviceCount): harmless here
+    # because the ranks are started as a CHILD process (subprocess.run), never by replacing this one (no exec)
+    have = torch.cuda.device_count()
     if have < args.gpus and os.environ.get("SIMPB_BENCH_DEVICE") is None:
         raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s); refusing to report a {args.gpus}-GPU "
                          "number from fewer (set SIMPB_BENCH_DEVICE only for the one-GPU rehearsal)")
@@ -271,6 +274,8 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if args.gpus is None:   # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world is the GPU count
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void msda_linear_fwd(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int live = m_live ? min(nq, *m_live) : nq;
   int cam = query_cam[q];
-  if (cam < 0 || q >= live) return;   // capacity slot: the product behind this kernel never reads its row
+  if (cam < 0 || q >= live) return;   // capacity slot: its row stays as the caller left it (plugin/ops.py: zeros unless the product behind skips it)
   cam = min(cam, num_cams - 1);
   const size_t qrow = (size_t)b * nq + q;
 

@@ -157,6 +157,8 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
                         and (self.num_heads, self.num_levels, self.num_points, self.embed_dims) == (8, 4, 4, 256)
                         and reference_points.shape[-1] == 2 and value.dim() == 3 and value.shape[0] % (bs * self.num_cams) == 0
                         and value.shape[-1] == 256 and query_cam is not None)
+        if kwargs.get("ref_depth2d") is not None:   # group_attn.py:219-222 zeroes those locations; SimPBHead never passes it
+            raise NotImplementedError("ref_depth2d masking is not used by SimPBHead")
         if linear_route:
             return self._forward_linear(raw_query, query_pos, identity, value, kwargs.get("value_f16"), reference_points,
                                         spatial_shapes, level_start_index, query_cam, m_live, keep_parts)
@@ -198,8 +200,6 @@ class QueryGroupMultiScaleDeformableAttention(BaseModule):
             offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
             sampling_locations = reference_points[:, :, None, :, None, :2] \
                 + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
-        if kwargs.get("ref_depth2d") is not None:
-            raise NotImplementedError("ref_depth2d masking is not used by SimPBHead")
         if kwargs.get("query_groups", None) is not None:
             self.query_groups = kwargs["query_groups"]
         if query_cam is None:

@@ -288,8 +288,8 @@ def msda_linear(tokens, spatial_shapes, level_start_index, raw, reference_points
     """Camera-grouped deformable sampling of the RAW camera tokens (csrc/msda_lin.hip): what
     QueryGroupMultiScaleDeformableAttention computes between its value_proj and its output_proj, with value_proj moved
     behind the sampling by linearity. tokens f16 or f32 [bs, cams, Nv, 256]; raw [bs, Nq, 384] = sampling_offsets |
-    attention logits of [query | pos]; reference_points [bs, Nq, (1,) 2]; -> agg f32 [bs, Nq, 2176] (rows of capacity
-    slots are left unwritten: the product behind it skips them)."""
+    attention logits of [query | pos]; reference_points [bs, Nq, (1,) 2]; -> agg f32 [bs, Nq, 2176] (with m_live the
+    rows of capacity slots are left unwritten: the product behind it skips them; without it they are zeros)."""
     _require_gpu(tokens, raw, reference_points, query_cam)
     if tokens.dtype not in (torch.float16, torch.float32) or not tokens.is_contiguous() or tokens.dim() != 4 or tokens.shape[-1] != 256:
         raise ValueError("msda_linear: contiguous f16 / f32 tokens [bs, cams, Nv, 256] expected")
@@ -306,7 +306,10 @@ def msda_linear(tokens, spatial_shapes, level_start_index, raw, reference_points
     query_cam = query_cam.contiguous().int()
     if rows != bs * nq or rrows != bs * nq or query_cam.numel() != nq:
         raise ValueError("msda_linear: one raw row, one reference point and one camera per query slot")
-    agg = torch.empty(bs, nq, MSDA_LINEAR_WIDTH, device=tokens.device, dtype=torch.float32)
+    # the kernel leaves the rows of capacity slots (query_cam < 0, slots behind m_live) unwritten. With m_live the product
+    # behind it skips them; without it (the reference's padded batch) that product reads every row, so they must hold
+    # numbers: zeros, what the grouped sampler (csrc/msda.hip) writes there
+    agg = (torch.empty if m_live is not None else torch.zeros)(bs, nq, MSDA_LINEAR_WIDTH, device=tokens.device, dtype=torch.float32)
     status = _lib.lib().simpb_msda_linear_forward(
         _ptr(agg), MSDA_LINEAR_WIDTH, _ptr(tokens), 1 if tokens.dtype == torch.float16 else 0, _ptr(spatial_shapes),
         _ptr(level_start_index), _ptr(rawt), ldraw, _ptr(reft), ldref, _ptr(query_cam),

@@ -129,9 +129,15 @@ def test_allocation_of_independent_streams_equals_batches_of_one(bs, capacity):
     assert int(r.overflow.item()) == any_over == (1 if capacity == 600 else 0)
 
 
-def test_msda_module_vs_reference_vectors():
-    """A6: QueryGroupMultiScaleDeformableAttention (product module: projections + msda_prep + grouped sampler kernel +
-    output_proj + cat) against the reference's own per-camera loop output (ops.npz:msda.out)."""
+@pytest.mark.parametrize("route", ["linear", "grouped"])
+def test_msda_module_vs_reference_vectors(route):
+    """A6: QueryGroupMultiScaleDeformableAttention against the reference's own per-camera loop output (ops.npz:msda.out),
+    through BOTH routes of the product module, asserting which one ran:
+    * linear (what a frame runs, routes.msda_linear; taken when the device-side camera table `query_cam` is passed, as
+      SimPBHead passes it): offsets | logits product -> simpb_msda_linear_forward on the RAW tokens -> folded
+      W_out . W_value product (csrc/msda_lin.hip, dense.fold_msda_linear);
+    * grouped (the drop-in operator's route): value_proj + msda_prep + grouped sampler kernel + output_proj."""
+    from simpb_amd.plugin import ops as P
     from simpb_amd.plugin.group_attn import QueryGroupMultiScaleDeformableAttention
     g = load_golden("ops.npz")
     m = QueryGroupMultiScaleDeformableAttention(batch_first=True, embed_dims=256, num_heads=8, num_levels=4, num_points=4,
@@ -151,11 +157,46 @@ def test_msda_module_vs_reference_vectors():
     lsi = torch.cat([ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]])
     groups = [tuple(x) for x in g["msda.groups"].tolist()]
     ref = torch.from_numpy(g["msda.ref"]).cuda()
-    with torch.no_grad():
-        out = m(query=q, query_pos=qpos, value=val, reference_points=ref.unsqueeze(2), spatial_shapes=ss,
-                level_start_index=lsi, query_groups=groups, key_padding_mask=None)
-    out = out.materialize() if hasattr(out, "materialize") else out
-    assert np.abs(out.cpu().numpy() - g["msda.out"]).max() < 2e-5 * max(1.0, float(np.abs(g["msda.out"]).max()))
+    calls = {"linear": [], "grouped": 0}
+    orig_lin, orig_grp = P.msda_linear, P.ms_deform_attn_grouped
+
+    def spy_lin(tokens, *a, **kw):
+        calls["linear"].append(tokens.dtype)
+        return orig_lin(tokens, *a, **kw)
+
+    def spy_grp(*a, **kw):
+        calls["grouped"] += 1
+        return orig_grp(*a, **kw)
+    import simpb_amd.plugin.group_attn as GA
+    P.msda_linear, GA.ms_deform_attn_grouped = spy_lin, spy_grp
+    extra = dict(query_cam=P.query_cam_from_groups(groups, 52, "cuda")) if route == "linear" else {}
+    flat = lambda o: o.materialize() if hasattr(o, "materialize") else o   # noqa: E731
+    try:
+        with torch.no_grad():
+            out = flat(m(query=q, query_pos=qpos, value=val, reference_points=ref.unsqueeze(2), spatial_shapes=ss,
+                         level_start_index=lsi, query_groups=groups, key_padding_mask=None, **extra))
+            tol = 2e-5 * max(1.0, float(np.abs(g["msda.out"]).max()))
+            assert np.abs(out.cpu().numpy() - g["msda.out"]).max() < tol
+            if route == "linear":
+                assert calls["linear"] == [torch.float32] and calls["grouped"] == 0
+                # the f16 token copy the FPN leaves (value_f16): TOK = _Float16 on tokens that are f16 numbers gives what
+                # TOK = float gives on the same numbers widened -- and that is the module's answer on those tokens by the
+                # grouped route too (value_proj over every token, the reference's order of operations)
+                v16 = val.half()
+                wide = flat(m(query=q, query_pos=qpos, value=v16.float(), reference_points=ref.unsqueeze(2), spatial_shapes=ss,
+                              level_start_index=lsi, query_groups=groups, **extra))
+                half = flat(m(query=q, query_pos=qpos, value=v16.float(), value_f16=v16, reference_points=ref.unsqueeze(2),
+                              spatial_shapes=ss, level_start_index=lsi, query_groups=groups, **extra))
+                assert calls["linear"] == [torch.float32, torch.float32, torch.float16] and calls["grouped"] == 0
+                assert float((half - wide).abs().max()) <= 1e-6 * max(1.0, float(wide.abs().max()))
+                grouped = flat(m(query=q, query_pos=qpos, value=v16.float(), reference_points=ref.unsqueeze(2), spatial_shapes=ss,
+                                 level_start_index=lsi, query_groups=groups))
+                assert calls["grouped"] == 1
+                assert float((half - grouped).abs().max()) <= tol
+            else:
+                assert calls["linear"] == [] and calls["grouped"] == 1
+    finally:
+        P.msda_linear, GA.ms_deform_attn_grouped = orig_lin, orig_grp
 
 
 def test_daf_kernel_vs_reference_fallback_vectors():

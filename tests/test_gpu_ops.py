@@ -120,6 +120,103 @@ def test_msda_grouped_vs_oracle(cfg):
     assert float((got - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1.0)
 
 
+def _msda_linear_case(seed, bs, nq, ncam, shapes, live, edge=True):
+    """Inputs of QueryGroupMultiScaleDeformableAttention.forward between its projections (group_attn.py:176-243): raw camera
+    tokens that ARE f16 numbers (what the fp16 FPN leaves), the [offsets | logits] row of every query, 2-d reference points
+    placed ON and just beyond every edge of the normalised image, offsets of up to +-3 pixels of each level -- so a large
+    share of the bilinear taps falls outside the map and the bias term of the linearity rewrite
+    (b_h . sum of valid tap weights, csrc/msda_lin.hip) differs visibly from a plain b_h."""
+    rs = np.random.RandomState(seed)
+    nv = sum(h * w for h, w in shapes)
+    tokens = torch.from_numpy(rs.standard_normal((bs, ncam, nv, 256)).astype(np.float32)).half().float()
+    raw = torch.from_numpy(np.concatenate([rs.uniform(-3, 3, (bs, nq, 256)), rs.standard_normal((bs, nq, 128)) * 2], -1).astype(np.float32))
+    ref = torch.from_numpy(rs.uniform(0.0, 1.0, (bs, nq, 2)).astype(np.float32))
+    if edge:   # every map edge and corner, exactly on it / one texel inside / beyond it
+        marks = [0.0, 1.0, 1e-3, 1 - 1e-3, -0.02, 1.02, 0.5]
+        k = 0
+        for mx in marks:
+            for my in marks:
+                if k < nq:
+                    ref[:, k, 0], ref[:, k, 1] = mx, my
+                    k += 1
+    ss = torch.tensor(shapes, dtype=torch.long)
+    lsi = torch.cat([ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]])
+    bounds = sorted(rs.choice(np.arange(live + 1), ncam - 1).tolist())
+    groups = list(zip([0] + bounds, bounds + [live]))   # camera groups over the live slots; [live, nq) are capacity slots
+    return tokens, raw, ref, ss, lsi, groups
+
+
+@pytest.mark.parametrize("tok", ["f16", "f32"])
+@pytest.mark.parametrize("use_m_live", [True, False], ids=["m_live", "no_m_live"])
+def test_msda_linear_route_vs_oracle(tok, use_m_live):
+    """The sampler a frame actually runs (simpb_msda_linear_forward, csrc/msda_lin.hip, TOK = _Float16 and float) together
+    with the folded [256, 2176] product behind it (dense.fold_msda_linear) against the oracle's
+    value_proj -> per-camera sampler -> output_proj (oracle/simpb_ref.py: qg_msda's arithmetic, group_attn.py:176-243) on
+    the same inputs: reference points on / beyond every map edge, capacity slots (query_cam = -1), a device-side live
+    count. Operator tolerance 2e-5 . max|ref|."""
+    import torch.nn as nn
+    R = _oracle()
+    ops = _ops()
+    from simpb_amd.plugin import dense
+    # (the device-side live count is a row count of the flat [bs * slots] operand, which the head only passes for a batch
+    # of one or for the flat slot array of independent streams: SimPBHead._m_live)
+    bs, nq, ncam, live = (1 if use_m_live else 2), 96, 6, 83
+    shapes = [(8, 22), (4, 11), (2, 6), (1, 3)]
+    tokens, raw, ref, ss, lsi, groups = _msda_linear_case(21, bs, nq, ncam, shapes, live)
+    torch.manual_seed(5)
+    vp, op = nn.Linear(256, 256), nn.Linear(256, 256)
+    with torch.no_grad():
+        vp.bias.normal_(0, 0.5)      # a bias of the size of the projected values: the wsum column must be right
+        op.bias.normal_(0, 0.1)
+    # ---- oracle: project every camera token, sample head slices camera by camera, project out
+    with torch.no_grad():
+        value = vp(tokens).view(bs, ncam, -1, 8, 32)
+        off = raw[..., :256].view(bs, nq, 8, 4, 4, 2)
+        aw = raw[..., 256:].view(bs, nq, 8, 16).softmax(-1).view(bs, nq, 8, 4, 4)
+        norm = torch.stack([ss[:, 1], ss[:, 0]], -1).float()
+        loc = ref[:, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
+        want = torch.zeros(bs, nq, 256)
+        for i, (s, e) in enumerate(groups):
+            if e > s:
+                want[:, s:e] = op(R.ms_deform_attn(value[:, i].contiguous(), ss, loc[:, s:e].contiguous(), aw[:, s:e].contiguous()))
+    # the bias term is non-trivial on this input: with a plain b_h instead of b_h . wsum the answer moves by far more than the tolerance
+    with torch.no_grad():
+        ones = R.ms_deform_attn(torch.ones(bs, sum(h * w for h, w in shapes), 8, 1), ss, loc[:, :live].contiguous(), aw[:, :live].contiguous())
+    assert float((1 - ones).abs().max()) > 0.5 and float((ones < 0.999).float().mean()) > 0.2
+    # ---- product: sampler on the raw tokens + folded product
+    qcam = torch.full((nq,), -1, dtype=torch.int32)    # the static slot array's table: capacity slots carry camera -1
+    for i, (s, e) in enumerate(groups):
+        qcam[s:e] = i
+    qcam = qcam.cuda()
+    assert int((qcam < 0).sum()) == nq - live
+    m_live = torch.tensor([live], dtype=torch.int32, device="cuda") if use_m_live else None
+    t = tokens.cuda().half() if tok == "f16" else tokens.cuda()
+    agg = ops.msda_linear(t.contiguous(), ss.cuda(), lsi.cuda(), raw.cuda(), ref.cuda(), qcam, m_live)
+    assert tuple(agg.shape) == (bs, nq, ops.MSDA_LINEAR_WIDTH)
+    if not use_m_live:
+        assert float(agg[:, live:].abs().max()) == 0.0   # capacity rows hold zeros when the product will read them
+    wsum = agg[:, :live, 2048:2056].cpu()
+    assert float((wsum - ones).abs().max()) < 1e-5   # [bs, live, 8 heads]: the valid tap weight of every head
+    assert float(agg[:, :live, 2056:].abs().max()) == 0.0
+    vp, op = vp.cuda(), op.cuda()
+    wf, bf = dense.fold_msda_linear(vp, op, 8, ops.MSDA_LINEAR_WIDTH)
+    got = dense.linear(agg, wf, bf, m_live=m_live)[:, :live].cpu()
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got - want[:, :live]).abs().max()) <= 2e-5 * scale, float((got - want[:, :live]).abs().max())
+
+
+def test_msda_linear_f16_tokens_equal_widened_f32_tokens():
+    """TOK = _Float16 and TOK = float read the same numbers and sum them in the same order: equal output rows."""
+    ops = _ops()
+    bs, nq, ncam, live = 1, 64, 6, 64
+    shapes = [(16, 44), (8, 22), (4, 11), (2, 6)]
+    tokens, raw, ref, ss, lsi, groups = _msda_linear_case(22, bs, nq, ncam, shapes, live)
+    qcam = ops.query_cam_from_groups(groups, nq, "cuda")
+    a16 = ops.msda_linear(tokens.cuda().half().contiguous(), ss.cuda(), lsi.cuda(), raw.cuda(), ref.cuda(), qcam)
+    a32 = ops.msda_linear(tokens.cuda().contiguous(), ss.cuda(), lsi.cuda(), raw.cuda(), ref.cuda(), qcam)
+    assert float((a16 - a32).abs().max()) <= 1e-6 * max(1.0, float(a32.abs().max()))
+
+
 def test_ops_reject_cpu_tensors():
     ops = _ops()
     with pytest.raises(RuntimeError):

@@ -1,6 +1,9 @@
 """GPU: the static-shape / hipGraph frame runner produces the reference's detections. Same golden
 streams as test_gpu_head.py, but through simpb_amd.runner.FrameRunner (fixed-capacity 2D query set,
 device-side group table, persistent bank buffers, captured warm frame)."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -555,16 +558,20 @@ def _matched_fraction(got, want, tol):
 
 def test_batch_of_independent_streams_frame_by_frame_from_the_same_state():
     """A batch of independent streams must return, stream by stream, what a runner of batch one returns for that stream:
-    bs = 4, one stream jumping in time, checked frame by frame FROM THE SAME STATE: before
+    bs = 4, real backbone, replayed graph, one stream jumping in time, checked frame by frame FROM THE SAME STATE: before
     frame f the plain batch-of-one runner of stream b is handed the bank state (cached features / anchors / confidences /
     track ids) the batched runner held for that stream, so a difference can only come from this frame's arithmetic.
-    Why not the whole stream: with random weights the decoder is chaotic -- the flat layout shifts the attention key tiles
-    of every stream but the first, results move by ~1e-5, and now and then that flips a top-k tie or an inside/outside
-    test of the allocation, after which a few instances differ by 1e-2 and the difference spreads through the bank
-    (tools/diag_ragged.py: bs = 4, stream 1 from frame 3 on; at bs = 3 a whole-stream comparison held for 8 frames until an
-    unrelated change of the FPN's tiling moved the features by an fp16 ulp, then stream 1 flipped at its jump frame). Criteria per (stream, frame): same
-    number of 3D rows, >= 97 % of the 3D rows (box, score, label) and >= 95 % of the 2D rows with a partner within
-    1e-3 (2D boxes in pixels: 0.1); and all rows in at least 85 % of the (stream, frame) pairs."""
+    Why not the whole stream: round 4 traced round 3's red whole-stream comparison (stream 1 around its jump frame)
+    operator by operator (tools/diag_ragged_trace.py, profiles/r04_ragged_trace_bs3.log): from the same state the flat layout
+    and the batch of one agree to <= 3e-5 of each record's scale on every operator boundary and on the state they leave
+    behind, jump frame included; what separates two whole streams is the random-weight decoder's sensitivity (one 2D
+    self-attention layer turns a 4e-5 input difference into 2e-3 on every row -- between two batch-of-ONE runs whose bank
+    differs by 1e-3 in five rows), not a tie and not the layout. The oracle form of this claim is
+    tests/test_gpu_head.py::test_batch_of_independent_streams_vs_oracle_per_stream.
+    Criterion: EVERY 3D row (box, score, label) and EVERY 2D row of every (stream, frame) pair has a partner within 1e-3
+    (2D boxes in pixels: 0.1) and the 2D counts agree -- except where the pair is accounted for by a tie that is logged
+    with its numbers: a ranking cut of the plain run (InstanceBank.update: rank 299 / 300 of the first layer's max-class
+    logits, instance_bank.py:137; the decoder's top 300 by score, decoder.py:145) within 1e-4 of flipping; at most 2 pairs."""
     from simpb_amd import configs, plugin
     from simpb_amd.runner import FrameRunner
     wh, bs, frames = (352, 128), 4, 8
@@ -606,10 +613,13 @@ def test_batch_of_independent_streams_frame_by_frame_from_the_same_state():
                                np.asarray(r["labels_2d"], np.float64)[:, None] * 10.0], axis=1)
 
     full = total = 0
+    partial = []
     for b in range(bs):
         replay = _ReplayModel(make().head)
         plain = FrameRunner(replay, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=False)
         mine = plain.head.instance_bank
+        seen_outs = {}
+        plain.head.register_forward_hook(lambda m, i, o: seen_outs.update(outs=o))
         for f in range(frames):
             if f >= 1:   # the state the batched runner's stream b had in front of this frame
                 torch.cuda.synchronize()
@@ -621,10 +631,23 @@ def test_batch_of_independent_streams_frame_by_frame_from_the_same_state():
             have = got[f][b]["img_bbox"]
             assert have["boxes_3d"].shape == want["boxes_3d"].shape
             m3, m2 = _matched_fraction(rows3(have), rows3(want), 1e-3), _matched_fraction(rows2(have), rows2(want), 1e-3)
-            assert m3 >= 0.97 and m2 >= 0.95, (b, f, m3, m2, len(have["boxes_2d"]), len(want["boxes_2d"]))
-            full += int(m3 == 1.0 and m2 == 1.0 and len(have["boxes_2d"]) == len(want["boxes_2d"]))
+            ok = m3 == 1.0 and m2 == 1.0 and len(have["boxes_2d"]) == len(want["boxes_2d"])
+            if not ok:   # only a ranking cut about to flip accounts for rows without a partner
+                o = seen_outs["outs"]
+                v = torch.sort(o["classification"][0][0].max(dim=-1).values, descending=True).values
+                sc = torch.sort(o["classification"][-1][0].sigmoid().max(dim=-1).values, descending=True).values
+                tie = dict(update_cut_gap=float(v[299] - v[300]), decode_cut_gap=float(sc[299] - sc[300]))
+                partial.append(dict(stream=b, frame=f, matched_3d=round(m3, 4), matched_2d=round(m2, 4),
+                                    n2d=(len(have["boxes_2d"]), len(want["boxes_2d"])), tie=tie))
+                assert min(tie.values()) < 1e-4, f"rows without a partner and no ranking cut within 1e-4 of flipping: {partial[-1]}"
+                assert m3 >= 0.99 and m2 >= 0.97, partial[-1]   # a flipped cut swaps one instance and its 2D queries, no more
+            full += int(ok)
             total += 1
-    assert full >= 0.85 * total, (full, total)
+    log_dir = os.environ.get("SIMPB_TEST_LOG_DIR")
+    if log_dir and os.path.isdir(log_dir):
+        with open(os.path.join(log_dir, "ragged_same_state_ties.json"), "w") as fh:
+            json.dump(dict(pairs=total, fully_matched=full, accounted_by_a_tie=partial), fh, indent=1)
+    assert len(partial) <= 2, (full, total, partial)
 
 
 def test_two_pipelined_runners_side_by_side():
