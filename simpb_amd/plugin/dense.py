@@ -22,14 +22,15 @@ MAX_SEGS, MAX_JOBS = 4, 4
 # host-folded weights). Off: one GEMM per nn.Linear plus the cat/add kernels around it, where every module boundary of
 # the reference exists -- kept for A/B measurements and as the route on which tests/test_gpu_head.py compares every
 # golden trace record.
-# routes.gemm_split_fp16: weights are also handed over split into two half-precision parts, and launches whose segments
-# are 128-aligned run on the FP16 matrix cores in four split passes at fp32-grade accuracy (csrc/gemm.hip:
-# gemm_f16x3_kernel; 25-35 % faster per launch, tests/test_dense.py bounds its error like the exact kernel's). Off
-# (shipped): always the exact fp32 matrix-core kernel, because the gain at frame level is small (296 -> 301 frames/s: the
-# launches are latency-, not matrix-bound) and because a different -- equally accurate -- rounding moved one 2D query of
-# the golden R50 stream across the image border (N2 1129 vs 1130 in one layer of one frame): the allocation's
-# inside/outside tests sit downstream of every product, ~1e-6 of the 583k point tests of a stream fall within rounding
-# distance of a border, and the golden vectors were matched slot for slot with the exact kernels.
+# routes.gemm_split_fp16 (shipped since round 4): weights are also handed over split into two half-precision parts, and
+# launches whose segments are 128-aligned run on the FP16 matrix cores in four split passes (csrc/gemm.hip:
+# gemm_f16x3_kernel: every partial product of x = xh + xl / 2^11 and W = Wh + Wl / 2^11, fp32 accumulators). Measured
+# against float64 on the decoder's shapes its error is about HALF that of the exact-fp32 matrix-core kernel
+# (profiles/r04_gemm_split_error.txt), tests/test_dense.py holds both to the same bound, and every golden / oracle / runner
+# test is green on it; -0.09 ms on the decoder's critical path. Off: always the v_mfma_f32_32x32x2_f32 kernel. Any
+# re-rounding CAN move a 2D query across an image border (~1e-6 of the 583k point tests of a stream fall within rounding
+# distance of one; a three-term form of this kernel did so on the golden R50 stream in round 1): what the golden vectors pin
+# is that this form does not on any fixture, not that it cannot.
 from . import routes
 
 

@@ -17,9 +17,14 @@ DEFAULTS = dict(
     # decoder dense layers as grouped segment-input GEMMs with host-folded weights (plugin/dense.py, csrc/gemm.hip).
     # False: one GEMM per nn.Linear plus the cat/add kernels around it -- every module boundary of the reference exists.
     dense=True,
-    # grouped GEMM on the FP16 matrix cores with split operands (fp32-grade, 25-35 % faster per launch, +2 % per frame):
-    # off, a differently rounded product moved one 2D query of the golden R50 stream across an image border (dense.py)
-    gemm_split_fp16=False,
+    # grouped GEMM on the FP16 matrix cores with split operands, all four partial products (x = xh + xl / 2^11 to 22 bits,
+    # fp32 accumulators; csrc/gemm.hip gemm_f16x3_kernel): against float64 its error is 0.45-0.6 x that of the exact-fp32
+    # matrix-core kernel on every decoder shape (profiles/r04_gemm_split_error.txt: products of f16 pairs are exact in
+    # fp32 and a 16-deep step rounds once), the whole GPU suite is green on it (profiles/r04_gputest_split.log: golden
+    # streams, oracle, runners), decoder graph 2.06 -> 1.96 ms. Shipped since round 4; False: the v_mfma_f32_32x32x2_f32
+    # kernel. (Rounds 1-3 left it off: an earlier three-term form moved one 2D query of the golden R50 stream across an
+    # image border -- any re-rounding can; the four-term form does not on any fixture.)
+    gemm_split_fp16=True,
     # MLP chains: 4-row workgroups on the 4x4 matrix blocks with k4-packed weights (csrc/mlp_chain.hip). False +
     # chain_transposed False: the 16-row matrix-core kernel on the weights as stored; chain_transposed: the VALU kernel.
     chain_rows4=True,
