@@ -183,6 +183,8 @@ int simpb_image_to_nhwc4_f16(void* out, const float* img, long long stride_n, lo
  * static 2D query set and are written as zeros. Deterministic. */
 #define SIMPB_GEMM_MAX_SEGS 4
 #define SIMPB_GEMM_MAX_JOBS 4
+#define SIMPB_GEMM_OUT_F32 0
+#define SIMPB_GEMM_OUT_SPLIT_HALFS 1
 typedef struct simpb_gemm_job {
   const float* x[SIMPB_GEMM_MAX_SEGS];
   int ldx[SIMPB_GEMM_MAX_SEGS];
@@ -193,7 +195,11 @@ typedef struct simpb_gemm_job {
   const float* bias;
   float* y;
   const int* m_live;
-  int ldw, ldy, relu, reserved;
+  int ldw, ldy, relu;
+  /* SIMPB_GEMM_OUT_F32 (0): y holds fp32 numbers. SIMPB_GEMM_OUT_SPLIT_HALFS (1): every element is written as the two halfs
+   * the split-operand attention kernel multiplies (simpb_attention_split_halfs): low 16 bits half(v), high 16 bits
+   * half((v - half(v)) * 2^11), in the element's own 32-bit word (ldy unchanged). Needs |v| < 65504. */
+  int out_fmt;
   /* optional rank-1 term before the ReLU: rows with row_flag[row] != 0 also get bias2[col]. This is
    * the 257th input column of ReWeight.reduce (models/aggregation.py:19-21,71-72: Linear over
    * cat(query2d, is_center)) without materialising the concatenation. Both NULL = absent. */
@@ -304,6 +310,23 @@ int simpb_conv3x3_group_tokens_f16(int num_levels, float* tokens, void* tokens_f
 int simpb_attention_f32(float* out, const float* q, const float* k, const float* v, const int* query_cam,
                         const int* group_start, int batch_size, int num_heads, int head_dim, int num_query,
                         int num_key, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+
+/* The same operator (same arguments, same layouts, fp32 in and out) on the FP16 matrix cores with split operands:
+ * every fp32 operand is carried as two halfs (x = xh + xl / 2^11, 22 bits), partial products are exact in fp32
+ * accumulators (csrc/attention.hip attention_f16s_kernel; fp32-grade: tests/test_gpu_ops.py holds it to the exact
+ * kernel's bound against float64). What a frame runs since round 4 (plugin/routes.py attention_split_fp16); operands
+ * must be inside the half-precision range (|x| < 65504: the decoder's projected queries / keys / values are O(10)). */
+int simpb_attention_f32_split(float* out, const float* q, const float* k, const float* v, const int* query_cam,
+                              const int* group_start, int batch_size, int num_heads, int head_dim, int num_query,
+                              int num_key, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+
+/* ... and on operands the producing GEMM already left split (simpb_gemm_job.out_fmt = SIMPB_GEMM_OUT_SPLIT_HALFS): every
+ * element of q / k / v is a 32-bit word holding half(x) in its low and half((x - half(x)) * 2^11) in its high 16 bits, at
+ * the position (same strides ldq / ldk / ldv, counted in 32-bit words) the fp32 element would have. The softmax scale is
+ * NOT applied here: the producer folds it into the query rows (1 / sqrt(64) is a power of two, so that is exact). */
+int simpb_attention_split_halfs(float* out, const void* q, const void* k, const void* v, const int* query_cam,
+                                const int* group_start, int batch_size, int num_heads, int head_dim, int num_query,
+                                int num_key, int ldq, int ldk, int ldv, int ldo, void* stream);
 
 /* Fused small-MLP chains: a whole `linear_relu_ln` stack (models/blocks.py:32-43) -- [Linear, ReLU]*,
  * LayerNorm, ..., optional last Linear and Scale -- in one launch; up to 8 independent chains over

@@ -37,6 +37,8 @@ SIGNATURES = {
     "simpb_linear_f16in_split": ([_P] * 5 + [_I] * 3 + [_P], _I),
     "simpb_format_tokens": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "simpb_attention_f32": ([_P] * 6 + [_I] * 9 + [_F, _P], _I),
+    "simpb_attention_f32_split": ([_P] * 6 + [_I] * 9 + [_F, _P], _I),
+    "simpb_attention_split_halfs": ([_P] * 6 + [_I] * 9 + [_P], _I),
     "simpb_mlp_chain_forward": ([_P, _P], _I),
     "simpb_bank_get": ([_P] * 6 + [_I] * 2 + [_F] * 2 + [_P], _I),
     "simpb_bank_update": ([_P] * 10 + [_I] * 5 + [_P], _I),

@@ -205,7 +205,7 @@ extern "C" int simpb_deformable_aggregation_forward(
 // 2: simpb_mlp_chain gained the post stage (8 chains per launch); 3: simpb_bank_cache takes the hold flags, the 3D
 // record carries the int64 track id in two lanes (15 columns); 5: simpb_gemm_job gained the LayerNorm prologue fields,
 // new entry points simpb_dfa_fused_forward / simpb_aggregate_2d_to_3d_alpha
-extern "C" int simpb_abi_version(void) { return 6; }
+extern "C" int simpb_abi_version(void) { return 7; }
 
 // ---- optional per-launch HIP-event timing (bench.py's roofline leg). Events are recorded on the
 // launch stream immediately around the kernel launch, inside the same C call, so the interval

@@ -54,6 +54,16 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// out_fmt = SIMPB_GEMM_OUT_SPLIT_HALFS: the element as the two halfs the split-operand attention kernel multiplies
+// (csrc/attention.hip unpack4), in the element's own 32-bit word
+__device__ __forceinline__ float out_word(float v, int fmt) {
+  if (fmt != SIMPB_GEMM_OUT_SPLIT_HALFS) return v;
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+  const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+  return __uint_as_float(bits);
+}
+
 struct GemmLaunch {
   simpb_gemm_args a;
   int tile_start[SIMPB_GEMM_MAX_JOBS + 1];
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(GemmLaunch L) {
       if (bias) v += bias[gc];
       if (job.row_flag && job.row_flag[gr]) v += job.bias2[gc];
       if (job.relu) v = fmaxf(v, 0.f);
-      y[(size_t)gr * job.ldy + gc] = gr < live ? v : 0.f;
+      y[(size_t)gr * job.ldy + gc] = gr < live ? out_word(v, job.out_fmt) : 0.f;
     }
   }
 }
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f16x3_kernel(GemmLaunch L) {
       if (bias) v += bias[gc];
       if (job.row_flag && job.row_flag[gr]) v += job.bias2[gc];
       if (job.relu) v = fmaxf(v, 0.f);
-      y[(size_t)gr * job.ldy + gc] = gr < live ? v : 0.f;
+      y[(size_t)gr * job.ldy + gc] = gr < live ? out_word(v, job.out_fmt) : 0.f;
     }
   }
 }

@@ -10,6 +10,7 @@ Folding only re-associates fp32 sums (differences ~1e-6 relative, covered by the
 the module tree and the state_dict are untouched, and the folded copies are rebuilt whenever a
 parameter is replaced or modified in place. GPU only: there is no CPU path behind these calls."""
 import ctypes
+import math
 
 import torch
 
@@ -52,7 +53,7 @@ class _Job(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p * MAX_SEGS), ("ldx", ctypes.c_int * MAX_SEGS), ("kseg", ctypes.c_int * MAX_SEGS),
                 ("num_seg", ctypes.c_int), ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
                 ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p), ("m_live", ctypes.c_void_p),
-                ("ldw", ctypes.c_int), ("ldy", ctypes.c_int), ("relu", ctypes.c_int), ("reserved", ctypes.c_int),
+                ("ldw", ctypes.c_int), ("ldy", ctypes.c_int), ("relu", ctypes.c_int), ("out_fmt", ctypes.c_int),
                 ("row_flag", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p)]
 
 
@@ -115,14 +116,15 @@ def rows2d(t):
     return t, rows, ld
 
 
-def job(xs, w, bias=None, relu=False, out=None, m_live=None, row_flag=None, bias2=None):
+def job(xs, w, bias=None, relu=False, out=None, m_live=None, row_flag=None, bias2=None, split_halfs=False):
     """One problem of a grouped launch: y = relu?([xs...] . w^T + bias [+ bias2 on rows whose
     row_flag != 0]). xs: tensor or list of tensors sharing their leading dimensions; w [N, K] (a row
     slice of a larger matrix is fine); out: optional destination [..., N] view (e.g. a column range
     of a wider buffer); row_flag i32 [rows], bias2 f32 [N]."""
     if torch.is_tensor(xs):
         xs = [xs]
-    return dict(xs=list(xs), w=w, bias=bias, relu=relu, out=out, m_live=m_live, row_flag=row_flag, bias2=bias2)
+    return dict(xs=list(xs), w=w, bias=bias, relu=relu, out=out, m_live=m_live, row_flag=row_flag, bias2=bias2,
+                split_halfs=split_halfs)
 
 
 def gemm(*jobs):
@@ -177,6 +179,9 @@ def gemm(*jobs):
         jb.bias = bias.data_ptr() if bias is not None else None
         jb.y, jb.ldy = out.data_ptr(), ldo
         jb.relu = 1 if spec["relu"] else 0
+        # split_halfs: every output element as the (hi, lo) half pair of csrc/attention.hip's split-operand kernel, in
+        # the element's own 32-bit word (the tensor is fp32-typed storage of those words: only that kernel reads it)
+        jb.out_fmt = 1 if spec.get("split_halfs") else 0
         ml = spec["m_live"]
         jb.m_live = ml.data_ptr() if ml is not None else None
         rf, b2 = spec.get("row_flag"), spec.get("bias2")
@@ -194,8 +199,8 @@ def gemm(*jobs):
     return outs
 
 
-def linear(xs, w, bias=None, relu=False, out=None, m_live=None, row_flag=None, bias2=None):
-    return gemm(job(xs, w, bias, relu, out, m_live, row_flag, bias2))[0]
+def linear(xs, w, bias=None, relu=False, out=None, m_live=None, row_flag=None, bias2=None, split_halfs=False):
+    return gemm(job(xs, w, bias, relu, out, m_live, row_flag, bias2, split_halfs))[0]
 
 
 def rowdot_sigmoid(x, w, b, m_live=None):
@@ -267,13 +272,17 @@ def _f64(t):
     return t.detach().double()
 
 
-def fold_mha_in(attn, pre, mode):
+def fold_mha_in(attn, pre, mode, q_scale=None):
     """Input side of an nn.MultiheadAttention fed with query = cat(f, pos) (E = 2 C wide) and
     value = pre(f) (pre = fc_before [E, C], no bias) or the query itself (pre None).
     mode 'qkv': rows [q; k; v] over [f | pos]; 'q': rows [q]; 'kv': rows [k; v].
+    q_scale: the softmax scale folded into the query rows (weight and bias), for the attention kernel that takes
+    pre-split operands (a power of two -- 1 / sqrt(64) -- so the projected queries are bit for bit scale * q).
     Returns (weight [rows, E], bias [rows])."""
     w, b = attn.in_proj_weight, attn.in_proj_bias
     e = attn.embed_dim
+    if q_scale is not None and (q_scale <= 0 or math.frexp(q_scale)[0] != 0.5):
+        raise ValueError("q_scale must be a power of two (folded exactly)")
 
     def build():
         if pre is None:
@@ -282,10 +291,14 @@ def fold_mha_in(attn, pre, mode):
             c = pre.weight.shape[1]
             wv = torch.cat([_f64(w[2 * e:]) @ _f64(pre.weight), torch.zeros(e, e - c, dtype=torch.float64, device=w.device)], 1)
         parts = {"qkv": [_f64(w[:e]), _f64(w[e: 2 * e]), wv], "q": [_f64(w[:e])], "kv": [_f64(w[e: 2 * e]), wv]}[mode]
-        bias = {"qkv": b, "q": b[:e], "kv": b[e:]}[mode]
-        return torch.cat(parts, 0).float().contiguous(), bias.detach().float().contiguous()
+        bias = {"qkv": b, "q": b[:e], "kv": b[e:]}[mode].detach().float().clone()
+        weight = torch.cat(parts, 0).float().contiguous()
+        if q_scale is not None and mode in ("qkv", "q"):
+            weight[:e] *= q_scale
+            bias[:e] *= q_scale
+        return weight, bias.contiguous()
 
-    return _folds.get(("mha_in", mode, pre is not None), (w, b, pre.weight if pre is not None else None), build, owner=attn)
+    return _folds.get(("mha_in", mode, pre is not None, q_scale), (w, b, pre.weight if pre is not None else None), build, owner=attn)
 
 
 def fold_mha_out(attn, post):

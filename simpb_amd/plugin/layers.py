@@ -170,20 +170,25 @@ def fused_graph_attention(layer, pre, post, query, query_pos, key=None, key_pos=
         return None
     if value is not None and (not isinstance(pre, nn.Linear) or pre.bias is not None):
         return None
+    # routes.attention_split_fp16: the projections leave q / k / v as the half pairs the split-operand attention kernel
+    # multiplies (softmax scale folded into the query rows), so that kernel converts nothing but its own probabilities
+    halfs = routes.R.attention_split_fp16
+    qs = 1.0 / math.sqrt(64.0) if halfs else None
     if key is None:
         if value is not None and value is not query:
             return None
-        w, b = dense.fold_mha_in(attn, pre if value is not None else None, "qkv")
-        qkv = dense.linear([query, query_pos], w, b, m_live=m_live)
+        w, b = dense.fold_mha_in(attn, pre if value is not None else None, "qkv", q_scale=qs)
+        qkv = dense.linear([query, query_pos], w, b, m_live=m_live, split_halfs=halfs)
         q, k, v = qkv[..., :e], qkv[..., e: 2 * e], qkv[..., 2 * e:]
     else:
         if key_pos is None or key.shape != key_pos.shape or (value is not None and value is not key) or query_cam is not None:
             return None
-        wq, bq = dense.fold_mha_in(attn, None, "q")
+        wq, bq = dense.fold_mha_in(attn, None, "q", q_scale=qs)
         wkv, bkv = dense.fold_mha_in(attn, pre if value is not None else None, "kv")
-        q, kv = dense.gemm(dense.job([query, query_pos], wq, bq), dense.job([key, key_pos], wkv, bkv))
+        q, kv = dense.gemm(dense.job([query, query_pos], wq, bq, split_halfs=halfs),
+                           dense.job([key, key_pos], wkv, bkv, split_halfs=halfs))
         k, v = kv[..., :e], kv[..., e:]
-    o = attention_f32(q, k, v, h, query_cam, group_start)
+    o = attention_f32(q, k, v, h, query_cam, group_start, split=2 if halfs else 0)
     wo, bo = dense.fold_mha_out(attn, post)
     return dense.report(post, dense.linear([o, query, query_pos], wo, bo, m_live=m_live))
 

@@ -343,10 +343,13 @@ def linear_f32(x, weight, bias=None, relu=False):
     return y.reshape(x.shape[:-1] + (n,))
 
 
-def attention_f32(q, k, v, num_heads, query_cam=None, group_start=None):
-    """softmax(q k^T / sqrt(hd)) v per head, fp32, flash style (csrc/attention.hip). q [bs, Nq, E],
+def attention_f32(q, k, v, num_heads, query_cam=None, group_start=None, split=None):
+    """softmax(q k^T / sqrt(hd)) v per head, fp32 in and out, flash style (csrc/attention.hip). q [bs, Nq, E],
     k/v [bs, Nk, E] with unit inner stride (row-strided views of a fused projection are fine), E =
-    num_heads * 64. With query_cam/group_start: camera-grouped self-attention over one slot set."""
+    num_heads * 64. With query_cam/group_start: camera-grouped self-attention over one slot set.
+    split: 0 / False = the exact-fp32 matrix instruction; 1 / True = the FP16 matrix cores with operands split inside the
+    kernel (fp32-grade); 2 = q / k / v ARE already the half pairs a GEMM with split_halfs=True left (plugin/dense.py; the
+    softmax scale folded into q): what a frame runs under routes.attention_split_fp16. None: 1 if that route is on."""
     _require_gpu(q, k, v)
     bs, nq, e = q.shape
     nk = k.shape[1]
@@ -372,10 +375,16 @@ def attention_f32(q, k, v, num_heads, query_cam=None, group_start=None):
             raise ValueError("grouped attention needs i32 query_cam [N] / group_start [cams+1] over one slot set")
     if nq == 0:
         return out
-    status = _lib.lib().simpb_attention_f32(
-        _ptr(out), _ptr(q), _ptr(k), _ptr(v), _ptr(query_cam) if query_cam is not None else None,
-        _ptr(group_start) if group_start is not None else None, bs, num_heads, hd, nq, nk, ldq, ldk, ldv, e,
-        1.0 / (hd ** 0.5), _stream())
+    from . import routes
+    mode = (1 if routes.R.attention_split_fp16 else 0) if split is None else int(split)
+    tables = (_ptr(query_cam) if query_cam is not None else None, _ptr(group_start) if group_start is not None else None)
+    if mode == 2:
+        status = _lib.lib().simpb_attention_split_halfs(_ptr(out), _ptr(q), _ptr(k), _ptr(v), *tables, bs, num_heads, hd, nq, nk,
+                                                        ldq, ldk, ldv, e, _stream())
+    else:
+        entry = _lib.lib().simpb_attention_f32_split if mode else _lib.lib().simpb_attention_f32
+        status = entry(_ptr(out), _ptr(q), _ptr(k), _ptr(v), *tables, bs, num_heads, hd, nq, nk, ldq, ldk, ldv, e,
+                       1.0 / (hd ** 0.5), _stream())
     _lib.check(status, "simpb_attention_f32")
     return out
 

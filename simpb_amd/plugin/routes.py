@@ -25,6 +25,13 @@ DEFAULTS = dict(
     # kernel. (Rounds 1-3 left it off: an earlier three-term form moved one 2D query of the golden R50 stream across an
     # image border -- any re-rounding can; the four-term form does not on any fixture.)
     gemm_split_fp16=True,
+    # attention core on the FP16 matrix cores with split operands (csrc/attention.hip attention_halfs_kernel): the
+    # projections in front of it leave q / k / v as (hi, lo) half pairs in each element's own 32-bit word (csrc/gemm.hip
+    # out_fmt, softmax scale folded into the query rows), S = three partial products, O = three, fp32 softmax in base 2.
+    # Same bound against float64 as the exact kernel (tests/test_gpu_ops.py), whole GPU suite green on it
+    # (profiles/r04_gputest_att.log); 900 x 900 x 8 heads 32 -> 20 us, decoder graph 1.95 -> 1.83 ms. Shipped since round 4.
+    # False: the exact-fp32 v_mfma_f32_32x32x2_f32 kernel on fp32 operands.
+    attention_split_fp16=True,
     # MLP chains: 4-row workgroups on the 4x4 matrix blocks with k4-packed weights (csrc/mlp_chain.hip). False +
     # chain_transposed False: the 16-row matrix-core kernel on the weights as stored; chain_transposed: the VALU kernel.
     chain_rows4=True,

@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(handle, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert handle.simpb_abi_version() == 6
+    assert handle.simpb_abi_version() == 7
 
 
 def test_bad_arguments_return_einval():

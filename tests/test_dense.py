@@ -186,9 +186,13 @@ def test_layernorm_segments_vs_torch(ks):
 
 
 @gpu
-def test_fused_graph_attention_matches_unfused_route():
+@pytest.mark.parametrize("halfs", [False, True], ids=["fp32_operands", "split_half_operands"])
+def test_fused_graph_attention_matches_unfused_route(halfs):
     """The three-launch block against the module route (cat, fc_before, nn.MultiheadAttention
-    arithmetic, + identity, fc_after) on the GPU, for the three call forms of the decoder."""
+    arithmetic, + identity, fc_after) on the GPU, for the three call forms of the decoder; with the projections handing
+    q / k / v to the attention core as fp32 numbers (exact-fp32 matrix instruction) and as split half pairs with the
+    softmax scale folded into the query rows (FP16 matrix cores, routes.attention_split_fp16)."""
+    from simpb_amd.plugin import routes
     from simpb_amd.plugin.layers import MultiheadAttention, fused_graph_attention
     torch.manual_seed(11)
     layer = MultiheadAttention(512, 8, batch_first=True, dropout=0.1).cuda().eval()
@@ -205,7 +209,7 @@ def test_fused_graph_attention_matches_unfused_route():
         v = pre(value) if value is not None else None
         return post(layer(q, k, v))
 
-    with torch.no_grad():
+    with torch.no_grad(), routes.override(attention_split_fp16=halfs):
         for query, key, value, kp in [(f, None, f, None), (f, tf, tf, tp), (f, None, None, None)]:
             got = fused_graph_attention(layer, pre, post, query, p, key, kp, value)
             want = unfused(query, key, value, p, kp)

@@ -23,7 +23,7 @@ def _oracle():
 
 def test_library_loaded():
     from simpb_amd import _lib
-    assert _lib.lib().simpb_abi_version() == 6
+    assert _lib.lib().simpb_abi_version() == 7
 
 
 def test_daf_golden_fallback_case():
@@ -365,19 +365,25 @@ def test_dfa_fused_launch_equals_three_launches(f16):
         assert float((wide - got).abs().max()) <= 2e-6 * max(1.0, float(got.abs().max()))
 
 
-@pytest.mark.parametrize("bs,nq,nk", [(1, 900, 600), (2, 77, 77), (1, 33, 1)])
-def test_attention_f32_vs_float64(bs, nq, nk):
+@pytest.mark.parametrize("split", [False, True], ids=["fp32_mfma", "split_fp16"])
+@pytest.mark.parametrize("bs,nq,nk,scale", [(1, 900, 600, 1.0), (2, 77, 77, 1.0), (1, 33, 1, 1.0), (1, 900, 900, 4.0)])
+def test_attention_f32_vs_float64(bs, nq, nk, scale, split):
+    """Both instantiations of the attention core (exact-fp32 matrix instruction; FP16 matrix cores with split operands,
+    what a frame runs) against float64, the same bound; scale 4: operands of magnitude ~16 and logits in the hundreds
+    (sharp softmax), where a 22-bit operand split must still hold."""
     rs = np.random.RandomState(8)
-    q = torch.from_numpy(rs.standard_normal((bs, nq, 512)).astype(np.float32))
-    k = torch.from_numpy(rs.standard_normal((bs, nk, 512)).astype(np.float32))
-    v = torch.from_numpy(rs.standard_normal((bs, nk, 512)).astype(np.float32))
-    got = _ops().attention_f32(q.cuda(), k.cuda(), v.cuda(), 8).cpu()
+    q = torch.from_numpy(rs.standard_normal((bs, nq, 512)).astype(np.float32)) * scale
+    k = torch.from_numpy(rs.standard_normal((bs, nk, 512)).astype(np.float32)) * scale
+    v = torch.from_numpy(rs.standard_normal((bs, nk, 512)).astype(np.float32)) * scale
+    got = _ops().attention_f32(q.cuda(), k.cuda(), v.cuda(), 8, split=split).cpu()
     qd, kd, vd = (t.double().reshape(bs, -1, 8, 64).transpose(1, 2) for t in (q, k, v))
     want = (torch.softmax(qd @ kd.transpose(-1, -2) / 8.0, -1) @ vd).transpose(1, 2).reshape(bs, nq, 512)
-    assert float((got.double() - want).abs().max()) < 2e-5
+    err = float((got.double() - want).abs().max())
+    assert err < 2e-5 * max(1.0, float(want.abs().max())), err
 
 
-def test_attention_f32_grouped_with_pads_and_strided_views():
+@pytest.mark.parametrize("split", [False, True], ids=["fp32_mfma", "split_fp16"])
+def test_attention_f32_grouped_with_pads_and_strided_views(split):
     """Camera-grouped form against the reference's formulation (dense scores + additive -inf block
     mask + nan_to_num, group_attn.py:104-131), with capacity pads (query_cam = -1), an empty group,
     and q/k passed as strided halves of one fused projection buffer."""
@@ -391,11 +397,59 @@ def test_attention_f32_grouped_with_pads_and_strided_views():
     v = torch.from_numpy(rs.standard_normal((bs, n, 512)).astype(np.float32))
     qk_d = qk.cuda()
     got = _ops().attention_f32(qk_d[..., :512], qk_d[..., 512:], v.cuda(), 8, cam.cuda(),
-                               torch.tensor(bounds, dtype=torch.int32).cuda()).cpu()
+                               torch.tensor(bounds, dtype=torch.int32).cuda(), split=split).cpu()
     mask = torch.full((n, n), float("-inf"), dtype=torch.float64)
     for c in range(6):
         mask[bounds[c]:bounds[c + 1], bounds[c]:bounds[c + 1]] = 0
     qd, kd, vd = (t.double().reshape(bs, n, 8, 64).transpose(1, 2) for t in (qk[..., :512], qk[..., 512:], v))
+    want = torch.nan_to_num(torch.softmax(qd @ kd.transpose(-1, -2) / 8.0 + mask, -1)) @ vd
+    want = want.transpose(1, 2).reshape(bs, n, 512)
+    assert float((got.double() - want).abs().max()) < 2e-5
+    assert float(got[:, 140:].abs().max()) == 0.0
+
+
+def _pack_split_halfs(x):
+    """fp32 -> the 32-bit words simpb_attention_split_halfs reads (what csrc/gemm.hip writes with out_fmt =
+    SIMPB_GEMM_OUT_SPLIT_HALFS): low 16 bits half(x), high 16 bits half((x - half(x)) * 2^11), fp32-typed storage."""
+    hi = x.half()
+    lo = ((x - hi.float()) * 2048.0).half()
+    word = (hi.view(torch.int16).to(torch.int32) & 0xFFFF) | (lo.view(torch.int16).to(torch.int32) << 16)
+    return word.view(torch.float32)
+
+
+@pytest.mark.parametrize("nq,nk,scale", [(900, 900, 1.0), (900, 600, 1.0), (77, 45, 1.0), (900, 900, 4.0), (33, 1, 1.0)])
+def test_attention_split_halfs_vs_float64(nq, nk, scale):
+    """What a frame runs (routes.attention_split_fp16): the eight-wave kernel on operands the producer already split,
+    softmax scale folded into q, strided views of one projection buffer; against float64, the exact kernel's bound."""
+    rs = np.random.RandomState(18)
+    n = max(nq, nk)
+    buf = torch.from_numpy(rs.standard_normal((2, n, 1536)).astype(np.float32)) * scale
+    q, k, v = buf[:, :nq, :512], buf[:, :nk, 512:1024], buf[:, :nk, 1024:]
+    packed = torch.cat([_pack_split_halfs(buf[..., :512] * 0.125), _pack_split_halfs(buf[..., 512:])], -1).cuda()
+    got = _ops().attention_f32(packed[:, :nq, :512], packed[:, :nk, 512:1024], packed[:, :nk, 1024:], 8, split=2).cpu()
+    qd, kd, vd = (t.double().reshape(2, -1, 8, 64).transpose(1, 2) for t in (q, k, v))
+    want = (torch.softmax(qd @ kd.transpose(-1, -2) / 8.0, -1) @ vd).transpose(1, 2).reshape(2, nq, 512)
+    err = float((got.double() - want).abs().max())
+    assert err < 2e-5 * max(1.0, float(want.abs().max())), err
+
+
+def test_attention_split_halfs_grouped_with_pads():
+    """... camera-grouped (an empty group, capacity slots, a partial last tile per group) against the reference's
+    formulation (dense scores + additive -inf block mask + nan_to_num, group_attn.py:104-131) in float64."""
+    rs = np.random.RandomState(19)
+    bs, n = 2, 150
+    bounds = [0, 40, 40, 77, 100, 131, 140]
+    cam = torch.full((n,), -1, dtype=torch.int32)
+    for c in range(6):
+        cam[bounds[c]:bounds[c + 1]] = c
+    buf = torch.from_numpy(rs.standard_normal((bs, n, 1536)).astype(np.float32))
+    packed = torch.cat([_pack_split_halfs(buf[..., :512] * 0.125), _pack_split_halfs(buf[..., 512:])], -1).cuda()
+    got = _ops().attention_f32(packed[..., :512], packed[..., 512:1024], packed[..., 1024:], 8, cam.cuda(),
+                               torch.tensor(bounds, dtype=torch.int32).cuda(), split=2).cpu()
+    mask = torch.full((n, n), float("-inf"), dtype=torch.float64)
+    for c in range(6):
+        mask[bounds[c]:bounds[c + 1], bounds[c]:bounds[c + 1]] = 0
+    qd, kd, vd = (t.double().reshape(bs, n, 8, 64).transpose(1, 2) for t in (buf[..., :512], buf[..., 512:1024], buf[..., 1024:]))
     want = torch.nan_to_num(torch.softmax(qd @ kd.transpose(-1, -2) / 8.0 + mask, -1)) @ vd
     want = want.transpose(1, 2).reshape(bs, n, 512)
     assert float((got.double() - want).abs().max()) < 2e-5
