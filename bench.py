@@ -61,6 +61,12 @@ def parse():
     ap.add_argument("--h2d", action="store_true",
                     help="frames start in pinned host memory and cross PCIe inside the timed step (async copy on the backbone "
                          "stream, beside the previous frame's decoder); default: inputs resident in HBM, as `value` requires")
+    ap.add_argument("--h2d-steps", type=int, default=30,
+                    help="steps of the secondary leg that repeats the measurement with the frames crossing PCIe (the reference's "
+                         "protocol); reported as reference_protocol_h2d, never as value; 0 = skip")
+    ap.add_argument("--capacity-by-rank", type=int, nargs="+", default=None, metavar="SLOTS",
+                    help="rehearsal only: the static 2D capacity of rank r (so that ONE rank overflows, re-runs and re-captures "
+                         "while the others keep submitting: the exchange must stay matched)")
     ap.add_argument("--lib", default=None,
                     help="measurement: load this build of the C-ABI library instead of the in-tree one (a variant built with "
                          "other compiler flags: python -c 'from simpb_amd import build; build.build_extension(extra_flags=[...], out=PATH)')")
@@ -173,12 +179,13 @@ class KernelMeter:
                               feature_bytes_per_element=s_f)
         d = self._durations(self.MSDA)
         if d and len(d) == len(self.msda_calls):
-            nbytes = 0.0
+            nbytes = survey = 0.0
             kernel, s_v = "msda_grouped_fwd", 4
             for call in self.msda_calls:
                 (bs, nq, heads, lvls, pts, _), ch, qcam = call[:3]
                 # capacity slots outside every camera group (query_cam < 0) are skipped by the kernel and not counted
                 nq = int((qcam >= 0).sum())
+                survey += bs * nq * (heads * lvls * pts * 4 * 32 * 4 + heads * lvls * pts * 3 * 4 + 256 * 4)   # N2 x (65 536 + 1 536 + 1 024) B
                 if len(call) > 3:
                     # sampling of the RAW tokens (csrc/msda_lin.hip: value_proj moved behind the sampling): per query
                     # heads*lvls*pts samples * 4 taps * 256 channels * token bytes + offsets|logits row + the 8 x 256 + tail row written
@@ -189,7 +196,8 @@ class KernelMeter:
                     # per query: heads*lvls*pts samples * 4 taps * ch * 4 B + loc + attn + out
                     nbytes += bs * nq * (heads * lvls * pts * 4 * ch * 4 + heads * lvls * pts * 3 * 4 + heads * ch * 4)
             n = len(d)
-            out["msda"] = dict(kernel=kernel, secs=sum(d) / n, nbytes=nbytes / n, launches=n, feature_bytes_per_element=s_v)
+            out["msda"] = dict(kernel=kernel, secs=sum(d) / n, nbytes=nbytes / n, launches=n, feature_bytes_per_element=s_v,
+                               survey_nbytes=survey / n)
         return out
 
 
@@ -251,6 +259,19 @@ def cpu_baseline(args):
                        f"(os.cpu_count()={os.cpu_count()}, affinity mask={share}: the threads are the box's CPU share, capped at 16)")
 
 
+def head_dtype_note():
+    """What the decoder computes in, as the route table has it for this run."""
+    from simpb_amd.plugin import routes
+    gemm = ("grouped GEMMs on the FP16 matrix cores with split operands (x = xh + xl / 2^11, all four partial products, fp32 accumulators: "
+            "error vs float64 0.45-0.6 x the exact-fp32 matrix kernel's, profiles/r04_gemm_split_error.txt)"
+            if routes.R.gemm_split_fp16 else "grouped GEMMs on the exact-fp32 matrix instruction")
+    att = ("attention on the FP16 matrix cores with split operands (three partial products per product, fp32 softmax; same bound vs "
+           "float64 as the exact kernel, tests/test_gpu_ops.py)" if routes.R.attention_split_fp16 else "attention on the exact-fp32 matrix instruction")
+    return ("f32 storage, f32 accumulation and fp32-grade products throughout (no bf16 / fp16-rounded operand anywhere in the head): "
+            f"{gemm}; {att}; MLP chains and samplers in plain fp32; the camera tokens are the fp16 backbone's output, sampled as they "
+            "are and accumulated in f32")
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, as the child
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` (one process per GPU),
@@ -307,7 +328,10 @@ def main():
     from simpb_amd.dist import DetectionGather
     from simpb_amd.runner import FrameRunner, PipelinedRunner, SplitPipelinedRunner
     torch.backends.cudnn.benchmark = not args.no_conv_search
-    total = args.prime + args.warmup + args.steps + args.meter_frames
+    # the secondary PCIe-inclusive leg (one GPU, one runner: its frames sit between the timed region and the roofline leg)
+    h2d_frames = 4 + args.h2d_steps if (not args.h2d and args.h2d_steps > 0 and world == 1 and args.streams == 1
+                                        and not args.no_pipeline and not args.eager) else 0
+    total = args.prime + args.warmup + args.steps + h2d_frames + args.meter_frames
     imgs = make_frames(args, device, total)
     if args.h2d:  # the reference's protocol times model(**data) with the scatter to the device inside (tools/benchmark.py:90-100)
         imgs = [x.cpu().pin_memory() for x in imgs]
@@ -322,6 +346,8 @@ def main():
     # bounds the frame (348 vs 335 frames/s); with several streams or a batch the chip is busy anyway and the extra
     # launches cost (8 streams: 368 vs 394 per GPU)
     split = pipelined and not args.no_split and args.streams == 1 and args.bs == 1
+    if args.capacity_by_rank:
+        args.capacity = args.capacity_by_rank[min(rank, len(args.capacity_by_rank) - 1)]
     runners = []
     for _ in range(args.streams):  # one model replica + runner per independent stream
         model = build_model(args, device)
@@ -331,9 +357,11 @@ def main():
     runner = runners[0]
     # N > 1: the fixed-shape device record of every stream to every rank, one all-gather per frame on a side stream
     gather = None
-    if dist is not None:   # 2D rows: anchors x cameras can never be exceeded, and every rank must use the same shape
+    if dist is not None:
+        # 2D rows: only the slots of the kept 3D boxes travel (compacted on the device): num_output x num_cams bounds them on
+        # every rank whatever its slot capacity is or grows to, so the exchange shape never has to be re-agreed
         gather = DetectionGather(args.streams * args.bs, runner.head.decoder.num_output, device,
-                                 rows2d=runner.head.num_anchor * runner.head.num_cams)
+                                 rows2d=runner.head.decoder.num_output * runner.head.num_cams, compact2d=True)
 
     def step(f, force_eager=False):
         if len(runners) == 1:
@@ -370,6 +398,26 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    # secondary figure: the reference's own timing protocol (tools/benchmark.py:90-100 times model(**data) with the scatter
+    # of the frame to the device inside). Never `value`: the same runner, the same streams, frames now starting in pinned
+    # host memory and crossing PCIe inside the step (async copy on the backbone stream, beside the previous frame's decoder)
+    h2d_leg = None
+    base = first + args.steps
+    if rank == 0 and world == 1 and h2d_frames and pipelined and len(runners) == 1:
+        pinned = [x.cpu().pin_memory() for x in imgs]   # the same ring of frames, now in pinned host memory
+        for f in range(base, base + 4):
+            runner.step(pinned[f % len(pinned)], metas[f])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for f in range(base + 4, base + h2d_frames):
+            runner.step(pinned[f % len(pinned)], metas[f])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        h2d_leg = dict(value=args.streams * args.bs * args.h2d_steps / dt, unit="frames/s", ms_per_step=dt / args.h2d_steps * 1e3,
+                       steps=args.h2d_steps,
+                       note="frames start in pinned host memory and cross PCIe inside the timed step (13 MB per 6-camera frame): the "
+                            "reference's protocol, tools/benchmark.py:90-100; `value` above has its inputs resident in HBM")
+
     # roofline leg: the next frames of the same streams, launched one kernel at a time (no graph) with
     # a HIP event pair recorded around every sampler launch. Event nodes cannot be read back from
     # inside a replayed graph, so the timed region above stays uninstrumented; rocprofv3 of this same
@@ -378,7 +426,7 @@ def main():
     if rank == 0 and args.meter_frames > 0:
         with KernelMeter(args.meter_frames) as kt:
             kt.start()
-            for f in range(first + args.steps, total):
+            for f in range(total - args.meter_frames, total):
                 runner.step(frame_of(f), metas[f], force_eager=True)  # rank-local: no collective here
             torch.cuda.synchronize()
             ksum = kt.summary()
@@ -434,6 +482,14 @@ def main():
                           "(SURVEY.md 8d), and the four taps of a sample and neighbouring samples share L2 lines, so it can still exceed the HBM peak"))
             if "valid_triples" in k:
                 r["valid_triples"] = k["valid_triples"]
+            if "survey_nbytes" in k:
+                # SURVEY.md 8(d)'s own byte count for the operator (the reference's head-slice sampler: 128-B fp32 slices of the
+                # PROJECTED map) over this kernel's time: the kernel gathers 4 x those bytes on purpose (whole 512-B f16 rows of
+                # the RAW tokens per head, which is what deletes the 11.8 GFLOP value_proj per layer), so `frac` above is a
+                # cache rate of the bytes it really touches and THIS is the fraction the survey's figure is priced at
+                r["survey_algorithmic_MB"] = k["survey_nbytes"] / 1e6
+                r["frac_survey_bytes"] = k["survey_nbytes"] / k["secs"] / 1e9 / HBM_PEAK_GBPS
+                r["frac_survey_bytes_at_rocprof_time"] = (k["survey_nbytes"] / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if prof_us else None
             return r
 
         roof = roofline(ksum["daf"], f"3D deformable aggregation ({ksum['daf']['kernel']}, {ksum['daf'].get('feature_bytes_per_element', 4)} B per token element)") if "daf" in ksum else None
@@ -445,11 +501,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"simpb_nus_r{args.depth}_img_{args.image_wh[0]}x{args.image_wh[1]}: 6-cam frames, "
-                                   f"ResNet{args.depth}+FPN on PyTorch-ROCm + HIP decoder, {args.streams} stream(s) x bs={args.bs} per GPU, temporal",
-                       "streams_per_gpu": args.bs * args.streams, "batch_semantics": ("one stream" if args.bs == 1 else "reference batch (groups padded to the max over the batch)" if args.reference_batch else f"{args.bs} independent streams per launch, each decoded as a batch of one (SURVEY.md 8e)"), "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "head_dtype": "f32 throughout (exact fp32 matrix instructions); the camera tokens are the fp16 backbone's output, sampled as they are and accumulated in f32", "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
+                                   f"ResNet{args.depth}+FPN (own HIP convolutions, fp16) + HIP decoder, PyTorch-ROCm as the host / memory / stream layer, "
+                                   f"{args.streams} stream(s) x bs={args.bs} per GPU, temporal",
+                       "streams_per_gpu": args.bs * args.streams, "batch_semantics": ("one stream" if args.bs == 1 else "reference batch (groups padded to the max over the batch)" if args.reference_batch else f"{args.bs} independent streams per launch, each decoded as a batch of one (SURVEY.md 8e)"), "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "head_dtype": head_dtype_note(), "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
                        if world > 1 else "single GPU", "inputs": "pinned host frames, H2D inside the timed step" if args.h2d else "resident in HBM",
                        "fp16_matrix_step": "2 x v_mfma_f32_32x32x8f16 (csrc/mfma_f16.h)", "num_query2d_last_frame": n2, "frame_runner": mode},
-            "roofline": roof, "roofline_msda": roof2,
+            "roofline": roof, "roofline_msda": roof2, "reference_protocol_h2d": h2d_leg,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -471,6 +471,15 @@ int simpb_decode2d_record_ragged(float* rec2d, const float* cls2d, const float* 
                                  int num_cams, int num_classes, int num_anchors, float crop_w, float crop_h, float crop_y0,
                                  float resize, void* stream);
 
+/* Exchange form of a 2D record (simpb_amd/dist.py): out f32 [bs, rows_out, 8] = the rows of rec2d [bs, rows_in, 8] that
+ * decode_with2d returns (rank >= 0 and camera >= 0: slots of the kept 3D boxes, decoder.py:176-251) in their order, pad rows
+ * (zeros, rank -1, camera -1) behind them. num_output x num_cams rows always suffice (one slot per anchor and camera), so
+ * the exchange shape does not depend on a runner's slot capacity. Rows past rows_out would be dropped (cannot happen at
+ * that size). out_stride / in_stride: floats between consecutive streams (multiples of 4; the output may be a column range
+ * of a wider send buffer). Both buffers 16-byte aligned. */
+int simpb_record2d_compact(float* out, long long out_stride, const float* rec2d, long long in_stride, int batch_size, int rows_in,
+                           int rows_out, void* stream);
+
 /* Top-k of each score row, sorted descending (ties: lower index first): values f32 [bs, k], indices
  * i32 [bs, k] from scores f32 [bs, n], n <= 2048, k <= n. What `topk` of models/instance_bank.py:13-20
  * and the ranking of SparseBox3DDecoder.decode (models/detection3d/decoder.py:145-167) ask of torch.topk /

@@ -10,6 +10,7 @@ _lib = None
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
+_LL = ctypes.c_longlong
 
 SIGNATURES = {
     "simpb_abi_version": ([], _I),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "simpb_bank_cache": ([_P] * 10 + [_I] * 6 + [_F, _I, _F, _P, _I, _P, _P], _I),
     "simpb_decode3d_record": ([_P] * 6 + [_I] * 4 + [_P], _I),
     "simpb_decode2d_record": ([_P] * 6 + [_I] * 4 + [_F] * 4 + [_P], _I),
+    "simpb_record2d_compact": ([_P, _LL, _P, _LL, _I, _I, _I, _P], _I),
     "simpb_decode2d_record_ragged": ([_P] * 7 + [_I] * 5 + [_F] * 4 + [_P], _I),
     "simpb_topk_rows": ([_P, _P, _P, _I, _I, _I, _P], _I),
     "simpb_rowdot_sigmoid": ([_P, _P, _I, _P, _P, _I, _I, _P, _P], _I),

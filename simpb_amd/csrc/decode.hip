@@ -196,6 +196,51 @@ __global__ __launch_bounds__(256) void decode2d_ragged_kernel(float* __restrict_
   *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
 }
 
+// Exchange form of the 2D record (simpb_amd/dist.py DetectionGather): only the rows decode_with2d returns -- slots whose
+// anchor is among the kept 3D boxes (rank >= 0, decoder.py:176-251) -- in their slot order, pad rows (rank -1, camera -1)
+// behind. At most num_output x num_cams rows exist (an anchor holds one slot per camera), whatever the runner's slot
+// capacity is and however it grows, so every rank can size its exchange buffer without talking to the others. One
+// workgroup per stream, stable ballot compaction.
+__global__ __launch_bounds__(256) void record2d_compact_kernel(float* __restrict__ out, const float* __restrict__ rec2d,
+                                                               int rows_in, int rows_out, long long in_stride,
+                                                               long long out_stride) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* in = rec2d + (size_t)b * in_stride;   // (strides in floats: the output may be a column range of a wider buffer)
+  float* o = out + (size_t)b * out_stride;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < rows_in; r0 += 256) {
+    const int r = r0 + tid;
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = make_float4(0.f, 0.f, -1.f, -1.f);
+    if (r < rows_in) {
+      lo = *reinterpret_cast<const float4*>(in + (size_t)r * 8);
+      hi = *reinterpret_cast<const float4*>(in + (size_t)r * 8 + 4);
+    }
+    simpb::loads_retired();
+    const bool keep = r < rows_in && hi.z >= 0.f && hi.w >= 0.f;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    const int dst = off + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep && dst < rows_out) {
+      *reinterpret_cast<float4*>(o + (size_t)dst * 8) = lo;
+      *reinterpret_cast<float4*>(o + (size_t)dst * 8 + 4) = hi;
+    }
+    simpb::stores_retired();
+    __syncthreads();
+    if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  for (int r = min(s_base, rows_out) + tid; r < rows_out; r += 256) {
+    *reinterpret_cast<float4*>(o + (size_t)r * 8) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(o + (size_t)r * 8 + 4) = make_float4(0.f, 0.f, -1.f, -1.f);
+  }
+}
+
 }  // namespace
 
 extern "C" int simpb_decode3d_record(float* rec3d, int* rank_of_anchor, const float* cls, const float* quality,
@@ -238,5 +283,17 @@ extern "C" int simpb_decode2d_record_ragged(float* rec2d, const float* cls2d, co
   hipLaunchKernelGGL(decode2d_ragged_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rec2d,
                      cls2d, box2d, q2a, query_cam, group_start, rank_of_anchor, batch_size, rows_per_stream, num_cams,
                      num_classes, num_anchors, crop_w, crop_h, crop_y0, 1.f / resize);
+  return simpb_check_launch();
+}
+
+extern "C" int simpb_record2d_compact(float* out, long long out_stride, const float* rec2d, long long in_stride, int batch_size,
+                                      int rows_in, int rows_out, void* stream) {
+  if (!out || !rec2d || batch_size <= 0 || rows_in <= 0 || rows_out <= 0 || batch_size > 65535 ||
+      ((reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(rec2d)) & 15) || out_stride < (long long)rows_out * 8 ||
+      in_stride < (long long)rows_in * 8 || ((out_stride | in_stride) & 3))
+    return SIMPB_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(record2d_compact_kernel, dim3(batch_size), dim3(256), 0, static_cast<hipStream_t>(stream), out, rec2d, rows_in,
+                     rows_out, in_stride, out_stride);
   return simpb_check_launch();
 }

@@ -90,13 +90,41 @@ def unpack_detections2d(record2d):
     return out
 
 
+def compact_record2d(rec2d, rows_out, out=None):
+    """[bs, rows, 8] -> [bs, rows_out, 8]: the rows decode_with2d returns (rank >= 0 and camera >= 0) in their order, pad
+    rows (zeros, rank -1, camera -1) behind. On the GPU one launch of csrc/decode.hip (simpb_record2d_compact); CPU tensors
+    (the gloo tests of the exchange) take the same statement in torch."""
+    bs, rows = rec2d.shape[:2]
+    if out is None:
+        out = torch.empty(bs, rows_out, RECORD2D_WIDTH, device=rec2d.device)
+    if rec2d.is_cuda:
+        from . import _lib
+        from .plugin.ops import _ptr, _stream
+        src = rec2d.contiguous().float()
+        if out.dtype != torch.float32 or tuple(out.shape) != (bs, rows_out, RECORD2D_WIDTH) or out.stride(2) != 1 or out.stride(1) != RECORD2D_WIDTH:
+            raise ValueError("compact_record2d: out must be f32 [bs, rows_out, 8] with dense rows (streams may be strided)")
+        _lib.check(_lib.lib().simpb_record2d_compact(_ptr(out), out.stride(0) if bs > 1 else rows_out * RECORD2D_WIDTH, _ptr(src),
+                                                     rows * RECORD2D_WIDTH, bs, rows, rows_out, _stream()), "simpb_record2d_compact")
+        return out
+    out.zero_()
+    out[..., 6:8] = -1.0
+    for b in range(bs):
+        kept = rec2d[b][(rec2d[b, :, 6] >= 0) & (rec2d[b, :, 7] >= 0)][:rows_out]
+        out[b, : kept.shape[0]] = kept
+    return out
+
+
 class DetectionGather:
     """The per-frame exchange: every rank's device records to every rank -- the 3D record [streams, num_output, 15] and,
     with rows2d > 0, the 2D record [streams, rows2d, 8] (decoder.py:230-251 returns boxes_2d / scores_2d / labels_2d /
     camidx_2d beside the 3D fields; apis/test.py:49-119 collects the whole dict) -- in ONE all_gather_into_tensor per
-    frame, off the compute streams. rows2d is a fixed exchange capacity equal on every rank (num_anchor x num_cams can
-    never be exceeded: an anchor holds at most one slot per camera); a runner's 2D record is copied into its leading rows
-    and the rest stay pad rows (camera = -1).
+    frame, off the compute streams. rows2d is a fixed exchange capacity equal on every rank:
+    * compact2d=True (what bench.py uses): rows2d = num_output x num_cams and a runner's record is COMPACTED on the device
+      to the rows decode_with2d returns (slots of the kept 3D boxes, at most one per box and camera) -- 1 800 rows for 300
+      boxes x 6 cameras whatever the runners' slot capacities are, so a rank whose 2D set overflows and grows its capacity
+      mid-stream (runner.py) changes nothing about the exchange, and the ranks never have to agree on a size;
+    * compact2d=False: the slot array itself, rows2d = num_anchor x num_cams (5 400: no set can exceed it); a runner's
+      record is copied into the leading rows, the rest stay pad rows (camera = -1).
 
     The send and receive buffers are persistent and owned by the side stream, so no allocator block crosses streams;
     the records handed to submit() are read on the side stream after it has waited for their producer streams and are
@@ -104,13 +132,14 @@ class DetectionGather:
     that live in a replayed graph's memory are protected by the runners: they make every graph that may write that memory
     wait for `done` (runner.rec_consumed). The host never waits inside submit(); result() waits for the last exchange."""
 
-    def __init__(self, streams, num_output, device, group=None, rows2d=0):
+    def __init__(self, streams, num_output, device, group=None, rows2d=0, compact2d=False):
         self.device = torch.device(device)
         self.group = group
         self.cuda = self.device.type == "cuda"
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.n3, self.rows2d = num_output * RECORD_WIDTH, int(rows2d)
+        self.compact2d = bool(compact2d) and self.rows2d > 0
         width = self.n3 + self.rows2d * RECORD2D_WIDTH
         self.send_buf = torch.zeros(streams, width, device=self.device)
         self.recv_buf = torch.zeros(self.world, streams, width, device=self.device)
@@ -143,6 +172,10 @@ class DetectionGather:
                 n, rows = r.shape[:2]
                 if r.shape[2] != RECORD2D_WIDTH:
                     raise ValueError(f"2D record {tuple(r.shape)} is not [*, rows, {RECORD2D_WIDTH}]")
+                if self.compact2d:   # only the rows of the kept 3D boxes, straight into the send buffer
+                    compact_record2d(r, self.rows2d, out=self.send2d[at:at + n])
+                    at += n
+                    continue
                 # a runner's slot array may be LONGER than the exchange capacity (capacities are rounded up to 128: 5 504 for
                 # 900 x 6), never its live part: live slots come first and there are at most num_anchor x num_cams of them
                 rows = min(rows, self.rows2d)

@@ -187,6 +187,10 @@ class PipelinedRunner(FrameRunner):
     set (`overflow_chain`, plugin/head.py), and collect() then re-runs both, in order, on the state frame t-1 found."""
 
     def __init__(self, model, batch_size, image_hw, capacity=1536, device=None, use_graph=True, independent_streams=False):
+        # two streams side by side from here on: a convolution that misses the in-tree kernels' shape rules must not slip to a
+        # vendor kernel silently (plugin/detector.py: STRICT_NO_VENDOR)
+        from .plugin import detector
+        detector.STRICT_NO_VENDOR = True
         super().__init__(model, batch_size, image_hw, capacity, device, use_graph, independent_streams)
         dev = self.device
         # the decoder of frame t is the critical path (a chain of ~170 dependent small launches); the

@@ -851,3 +851,39 @@ def test_conv1x1_with_input_bias_relu(cin, cout, h, w, res):
     want = conv1x1_nhwc(bias_act_(x.clone(), b_in, None, relu=True), wt, b, r, relu=True)
     got = conv1x1_nhwc(x, wt, b, r, relu=True, input_bias=b_in)
     assert torch.equal(got, want)
+
+
+@gpu
+def test_vendor_convolution_fallback_warns_and_is_refused_beside_a_decoder():
+    """A bottleneck whose channel counts miss the in-tree kernels' rules (48 input channels) goes to the vendor convolution:
+    with a RuntimeWarning when the module runs on its own, with a RuntimeError once a pipelined runner has declared that the
+    backbone runs beside a decoder (plugin/detector.py STRICT_NO_VENDOR), and silently when the route was switched off on
+    purpose (the tests' vendor cross-check)."""
+    import warnings
+    from simpb_amd.plugin import detector, routes
+    blk = detector.Bottleneck(48, 16).cuda().half().eval().to(memory_format=torch.channels_last)
+    for m in (blk.conv1, blk.conv2, blk.conv3):   # as SimPB.fuse_conv_bn leaves them: biases instead of BatchNorm
+        m.bias = torch.nn.Parameter(torch.zeros(m.out_channels, device="cuda", dtype=torch.float16))
+    blk.bn1 = blk.bn2 = blk.bn3 = torch.nn.Identity()
+    blk.downsample = torch.nn.Sequential(torch.nn.Conv2d(48, 64, 1, bias=True).cuda().half())
+    blk.fused_epilogue = True
+    x = torch.randn(2, 48, 8, 8, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    old, old_seen = detector.STRICT_NO_VENDOR, set(detector._warned)
+    try:
+        detector.STRICT_NO_VENDOR = False
+        detector._warned.clear()
+        with torch.no_grad(), warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            y = blk(x)
+        assert y.shape == (2, 64, 8, 8) and any("vendor convolution" in str(w.message) for w in caught)
+        detector.STRICT_NO_VENDOR = True
+        with torch.no_grad(), pytest.raises(RuntimeError, match="pipelined runner"):
+            blk(x)
+        with torch.no_grad(), routes.override(conv1x1_kernel=False, conv3x3_kernel=False), warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            blk(x)
+        assert not any("vendor convolution" in str(w.message) for w in caught)
+    finally:
+        detector.STRICT_NO_VENDOR = old
+        detector._warned.clear()
+        detector._warned.update(old_seen)

@@ -175,3 +175,80 @@ def test_detection_gather_takes_a_slot_array_longer_than_the_exchange_capacity()
     assert tuple(out.shape) == (1, 2, rows2d, 8) and torch.equal(out[0], rec2d[:, :rows2d])
     got = unpack_detections2d(out[0])
     assert len(got[0]["boxes_2d"]) == 5 and len(got[1]["boxes_2d"]) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The exchange bench.py uses since round 4: compact2d=True -- only the 2D rows of the kept 3D boxes travel, compacted into a
+# fixed num_output x num_cams rows, so the exchange shape does not depend on any runner's slot capacity.
+COMPACT_ROWS = 64
+
+
+def _runner_record2d(stream, frame, rows):
+    """A runner's 2D record with `rows` slots (its static capacity at that frame): live slots first, a third of them
+    belonging to kept 3D boxes (rank >= 0), capacity slots (camera -1) behind."""
+    g = torch.Generator().manual_seed(991 * frame + stream)
+    live = 30 + (frame * 7 + stream * 3) % 12
+    rec = torch.zeros(1, rows, RECORD2D_WIDTH)
+    rec[0, :, 6:8] = -1.0
+    rec[0, :live, :5] = torch.rand(live, 5, generator=g)
+    rec[0, :live, 5] = torch.randint(0, 10, (live,), generator=g).float()
+    rank = torch.randint(0, 300, (live,), generator=g).float()
+    rank[torch.rand(live, generator=g) > 0.35] = -1.0
+    rec[0, :live, 6] = rank
+    rec[0, :live, 7] = torch.sort(torch.randint(0, 6, (live,), generator=g)).values.float()
+    return rec
+
+
+def _capacity(rank, frame):
+    """Rank 1's runner overflows at frame 3: it re-runs the frame at a larger capacity and re-captures its graphs
+    (runner.py), so from then on its 2D record has 2304 rows instead of 1536 / 48; rank 0 never changes."""
+    return 48 if rank == 0 or frame < 3 else 176
+
+
+def _overflow_worker(rank, world, port, q):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_streams(2, rank, world)
+    gather = DetectionGather(len(mine), 300, torch.device("cpu"), rows2d=COMPACT_ROWS, compact2d=True)
+    seen = []
+    for frame in range(6):
+        if rank == 1 and frame == 3:
+            time.sleep(0.3)   # the re-run + re-capture happen INSIDE the runner's step: one submit per step, only later
+        gather.submit(_device_records(mine, frame), records2d=[_runner_record2d(s, frame, _capacity(rank, frame)) for s in mine])
+        seen.append((gather.result().numpy().view("int32").copy(), gather.result2d().numpy().copy()))
+    q.put((rank, gather.frames, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compact_exchange_is_untouched_by_a_rank_whose_runner_overflows_mid_stream():
+    """World 2 over gloo: rank 1's runner overflows at frame 3 (its step takes longer and its 2D record grows from 48 to
+    176 rows) while rank 0 keeps submitting. The exchange carries the compacted 2D rows, so its shape never changes: six
+    steps = six matched collectives on both ranks, and every frame's gathered 3D and 2D records are the runners' records
+    (3D bit for bit, 2D = the rows of the kept boxes in slot order, pad rows behind) on both ranks."""
+    from simpb_amd.dist import compact_record2d
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, frames, seen in got:
+        assert frames == 6 and len(seen) == 6
+        for frame, (rec3d, rec2d) in enumerate(seen):
+            assert rec3d.shape == (2, 1, 300, RECORD_WIDTH) and rec2d.shape == (2, 1, COMPACT_ROWS, RECORD2D_WIDTH)
+            for src in range(2):   # the record of stream `src` (owned by rank `src`) as every rank holds it
+                want3d = _device_records([src], frame)[0]
+                assert (rec3d[src] == want3d.numpy().view("int32")).all()
+                full = _runner_record2d(src, frame, _capacity(src, frame))
+                want2d = compact_record2d(full, COMPACT_ROWS)
+                assert torch.equal(torch.from_numpy(rec2d[src]), want2d)
+                kept = full[0][(full[0, :, 6] >= 0) & (full[0, :, 7] >= 0)]
+                a, b = unpack_detections2d(torch.from_numpy(rec2d[src]))[0], unpack_detections2d(full)[0]
+                assert len(kept) > 3 and torch.equal(a["boxes_2d"], b["boxes_2d"]) and torch.equal(a["rank3d"], b["rank3d"])
+                assert torch.equal(a["camidx_2d"], b["camidx_2d"])

@@ -328,8 +328,9 @@ def test_config3_eight_streams_per_gpu_vs_golden(split):
             compare_result(out[f][0]["img_bbox"], g, f"f{f}.res0.")
 
 
+@pytest.mark.parametrize("compact", [False, True], ids=["slot_array", "compacted_rows"])
 @pytest.mark.parametrize("split", [False, True])
-def test_gathered_record_survives_two_more_steps_before_it_is_read(split):
+def test_gathered_record_survives_two_more_steps_before_it_is_read(split, compact):
     """The exchange's asynchronous window: the device records (3D and 2D) of the frame step(t) returned are SUBMITTED to
     dist.DetectionGather without waiting for the exchange, the runner goes on for two more steps (replayed graphs: part
     A of frame t+2 shares part B's memory pool and is enqueued on the other stream), and only then the gathered record is
@@ -340,7 +341,9 @@ def test_gathered_record_survives_two_more_steps_before_it_is_read(split):
     g = load_golden("head_r50.npz")
     spec = spec_of(g)
     model, runner = _golden_pipelined_runner(spec, split)
-    gather = DetectionGather(1, 300, torch.device("cuda"), rows2d=900 * 6)
+    # compact: the exchange bench.py uses -- only the rows of the kept 3D boxes travel (csrc/decode.hip record2d_compact_kernel),
+    # 300 x 6 rows whatever the runner's slot capacity is; otherwise the slot array itself (900 x 6 rows)
+    gather = DetectionGather(1, 300, torch.device("cuda"), rows2d=300 * 6 if compact else 900 * 6, compact2d=compact)
     spin = torch.empty(64 * 1024 * 1024, device="cuda")
     frames, pending, checked = 30, [], 0
     for f in range(frames):
@@ -355,6 +358,10 @@ def test_gathered_record_survives_two_more_steps_before_it_is_read(split):
             got2d = unpack_detections2d(gather.result2d()[0])[0]
             assert torch.equal(got2d["boxes_2d"], want["boxes_2d"]) and torch.equal(got2d["scores_2d"], want["scores_2d"])
             assert torch.equal(got2d["labels_2d"], want["labels_2d"]) and torch.equal(got2d["camidx_2d"], want["camidx_2d"])
+            if compact:   # kept rows in front, nothing but pad rows behind, and the host decode of the compacted record = the frame's
+                raw = gather.result2d()[0, 0].cpu()
+                n = len(want["boxes_2d"])
+                assert bool((raw[:n, 6] >= 0).all()) and bool((raw[n:, 6:8] == -1).all()) and float(raw[n:, :6].abs().max()) == 0.0
             checked += 1
         if res is not None and not pending and f >= 8:   # replayed frames only, one exchange in flight at a time
             with torch.cuda.stream(gather.side):   # keep the side stream busy: the copy below stays pending for a while

@@ -7,7 +7,7 @@ rounds=${4:-3}
 for i in $(seq $rounds); do
   for v in A B; do
     if [ $v = A ]; then args="$2"; else args="$3"; fi
-    python bench.py --steps 150 --warmup 6 --meter-frames 0 --no-cpu-baseline $args 2>/dev/null | python -c "
+    python bench.py --steps 150 --warmup 6 --meter-frames 0 --h2d-steps 0 --no-cpu-baseline $args 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$v', '$args', round(d['ms_per_step'],4), round(d['value'],1))" >> gpurun_out/$1_ab.txt
   done
 done
