@@ -436,6 +436,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    if rank != 0:   # (rank 0 prints the line; the others leave what their runners did on stderr: rehearsals look for overflows there)
+        print(f"[rank {rank}] frame_runner {dict(runner.stats, capacity_2d=runner.capacity)}", file=sys.stderr, flush=True)
     if rank == 0:
         frames = world * args.streams * args.bs * args.steps
         head0 = runner.head

@@ -28,6 +28,7 @@
 //  * Workgroups are numbered so that each XCD (blockIdx % 8) walks a contiguous range of tiles:
 //    neighbouring tiles share their X rows in that XCD's L2.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include "../../include/simpb_hip.h"
 #include "mfma_f16.h"
@@ -419,6 +420,169 @@ __global__ __launch_bounds__(kThreads) void gemm_f16x3_kernel(GemmLaunch L) {
   }
 }
 
+// ---- the split-operand GEMM for launches with MANY output tiles (every product of a batch of streams): 64 x 128 output tiles, one 32 x 32 tile per wave over the WHOLE K. Why a second form: with
+// the matrix work down to four half-rate-free passes the 32 x 64 tiles above are bound by what they pull through L2 -- a
+// 900 x 512 -> 1 536 projection re-reads x 24 times and W 29 times, 134 MB per launch, ~13 us at the ~10 TB/s the L2 gives
+// 696 small workgroups -- and by one barrier + one cross-wave reduction per 16-deep step. Here x is re-read 12 times and W 15
+// times (67 MB), a wave issues 32 matrix instructions per barrier instead of 8, and nothing is reduced across waves: the
+// accumulators go straight to memory. Operands staged exactly as above (x split while staged, W pre-split, 144-byte LDS pitch).
+constexpr int kWM = 64, kWN = 128;
+
+template <int DEPTH>
+__global__ __launch_bounds__(kThreads) void gemm_f16x3_wide_kernel(GemmLaunch L) {
+  static_assert(DEPTH == 2, "two register sets, two LDS buffers");
+  constexpr int BKT = 64;
+  constexpr int LDH = BKT + 8;
+  constexpr int C4 = BKT / 4, NX4 = kWM * C4 / kThreads, RSX = kThreads / C4;   // x: 64 x 64 fp32 = 1024 float4, 2 per thread
+  constexpr int C8 = BKT / 8, NW8 = kWN * C8 / kThreads, RSW = kThreads / C8;   // w: 128 x 64 halfs = 1024 x 16 B, 2 per thread (hi and lo each)
+  static_assert(NX4 == 2 && NW8 == 2, "tile / thread split");
+  __shared__ __attribute__((aligned(16))) _Float16 s_xh[2 * kWM * LDH];
+  __shared__ __attribute__((aligned(16))) _Float16 s_xl[2 * kWM * LDH];
+  __shared__ __attribute__((aligned(16))) _Float16 s_wh[2 * kWN * LDH];
+  __shared__ __attribute__((aligned(16))) _Float16 s_wl[2 * kWN * LDH];
+
+  const int total = L.tile_start[L.a.num_jobs];
+  const int tile = (blockIdx.x & 7) * L.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= L.per_xcd || tile >= total) return;
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < SIMPB_GEMM_MAX_JOBS; ++t)
+    if (t < L.a.num_jobs && tile >= L.tile_start[t]) j = t;
+  const simpb_gemm_job& job = L.a.job[j];
+  const int local = tile - L.tile_start[j];
+  const int tiles_n = (job.N + kWN - 1) / kWN;
+  const int row0 = (local / tiles_n) * kWM;
+  const int col0 = (local % tiles_n) * kWN;
+  const int M = job.M, N = job.N, K = job.K;
+  const int live = job.m_live ? min(M, *job.m_live) : M;
+
+  const int tid = threadIdx.x;
+  float* __restrict__ y = job.y;
+  if (row0 >= live) {  // capacity rows: zeros
+    for (int idx = tid; idx < kWM * kWN; idx += kThreads) {
+      const int r = idx / kWN, c = idx - r * kWN;
+      if (row0 + r < M && col0 + c < N) y[(size_t)(row0 + r) * job.ldy + col0 + c] = 0.f;
+    }
+    return;
+  }
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, kb = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;   // this wave's 32 x 32 tile: rows 32 wm.., columns 32 wn..
+
+  const int srx = tid / C4, scx = tid % C4;
+  const int srw = tid / C8, scw = tid % C8;
+  f32x4 px[DEPTH][NX4];
+  h16x8 pwh[DEPTH][NW8], pwl[DEPTH][NW8];
+  const _Float16* __restrict__ wh = static_cast<const _Float16*>(job.w_hi);
+  const _Float16* __restrict__ wl = static_cast<const _Float16*>(job.w_lo);
+  unsigned xrow[NX4], wofs[NW8];
+#pragma unroll
+  for (int i = 0; i < NX4; ++i) xrow[i] = (unsigned)min(row0 + srx + RSX * i, live - 1);
+#pragma unroll
+  for (int i = 0; i < NW8; ++i) wofs[i] = (unsigned)min(col0 + srw + RSW * i, N - 1) * (unsigned)K + scw * 8;
+  const int nchunks = K / BKT;
+  const float* const x0 = job.x[0];
+  const float* const x1 = job.x[1];
+  const float* const x2 = job.x[2];
+  const float* const x3 = job.x[3];
+  const int e1 = job.kseg[0], e2 = e1 + (job.num_seg > 1 ? job.kseg[1] : 0), e3 = e2 + (job.num_seg > 2 ? job.kseg[2] : 0);
+  const unsigned l0 = job.ldx[0], l1 = job.ldx[1], l2 = job.ldx[2], l3 = job.ldx[3];
+
+  auto fetch = [&](auto set_c, int chunk) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    const int k0 = min(chunk, nchunks - 1) * BKT;   // (past the end: the last chunk again, never used -- loads stay unconditional)
+    const float* xs = x0 + k0;
+    unsigned ldx = l0;
+    if (k0 >= e1) { xs = x1 + (k0 - e1); ldx = l1; }
+    if (k0 >= e2) { xs = x2 + (k0 - e2); ldx = l2; }
+    if (k0 >= e3) { xs = x3 + (k0 - e3); ldx = l3; }
+    static_for<0, NX4>([&](auto i) __attribute__((always_inline)) {
+      px[set][decltype(i)::value] = *reinterpret_cast<const f32x4*>(xs + (xrow[decltype(i)::value] * ldx + scx * 4));
+    });
+    static_for<0, NW8>([&](auto i) __attribute__((always_inline)) {
+      pwh[set][decltype(i)::value] = *reinterpret_cast<const h16x8*>(wh + k0 + wofs[decltype(i)::value]);
+      pwl[set][decltype(i)::value] = *reinterpret_cast<const h16x8*>(wl + k0 + wofs[decltype(i)::value]);
+    });
+  };
+  auto stash = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    constexpr int buf = set & 1;
+    static_for<0, NX4>([&](auto i) __attribute__((always_inline)) {
+      constexpr int ii = decltype(i)::value;
+      const f32x4 v = px[set][ii];
+      h16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        hi[e] = h;
+        lo[e] = (_Float16)((v[e] - (float)h) * 2048.f);
+      }
+      *reinterpret_cast<h16x4*>(&s_xh[(buf * kWM + srx + RSX * ii) * LDH + scx * 4]) = hi;
+      *reinterpret_cast<h16x4*>(&s_xl[(buf * kWM + srx + RSX * ii) * LDH + scx * 4]) = lo;
+    });
+    static_for<0, NW8>([&](auto i) __attribute__((always_inline)) {
+      constexpr int ii = decltype(i)::value;
+      *reinterpret_cast<h16x8*>(&s_wh[(buf * kWN + srw + RSW * ii) * LDH + scw * 8]) = pwh[set][ii];
+      *reinterpret_cast<h16x8*>(&s_wl[(buf * kWN + srw + RSW * ii) * LDH + scw * 8]) = pwl[set][ii];
+    });
+  };
+
+  f32x16 acc, acs, act;   // leading term / cross terms (x 2^11) / trailing term (x 2^22), as gemm_f16x3_kernel
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acs[r] = 0.f; act[r] = 0.f; }
+
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int st = 0; st < BKT / 16; ++st) {
+      const int off = 16 * st + 8 * kb;  // lane (r32, kb) holds k = 16 st + 8 kb .. +7 of its x row / W row
+      const h16x8 ah = *reinterpret_cast<const h16x8*>(&s_xh[(buf * kWM + wm * 32 + r32) * LDH + off]);
+      const h16x8 al = *reinterpret_cast<const h16x8*>(&s_xl[(buf * kWM + wm * 32 + r32) * LDH + off]);
+      const h16x8 bh = *reinterpret_cast<const h16x8*>(&s_wh[(buf * kWN + wn * 32 + r32) * LDH + off]);
+      const h16x8 bl = *reinterpret_cast<const h16x8*>(&s_wl[(buf * kWN + wn * 32 + r32) * LDH + off]);
+      act = simpb::mfma_32x32x16_f16(al, bl, act);
+      acs = simpb::mfma_32x32x16_f16(al, bh, acs);
+      acs = simpb::mfma_32x32x16_f16(ah, bl, acs);
+      acc = simpb::mfma_32x32x16_f16(ah, bh, acc);
+    }
+  };
+
+  // chunk c lives in register set / LDS buffer c & 1: fetched two chunks ahead, stashed one barrier ahead of its product
+  static_for<0, DEPTH>([&](auto d) __attribute__((always_inline)) { fetch(d, decltype(d)::value); });
+  const int pairs = nchunks / 2;
+  for (int g = 0; g < pairs; ++g) {
+    static_for<0, DEPTH>([&](auto d) __attribute__((always_inline)) {
+      stash(d);
+      __syncthreads();
+      fetch(d, (g + 1) * DEPTH + decltype(d)::value);
+      multiply(decltype(d)::value & 1);
+    });
+  }
+  if (nchunks & 1) {
+    stash(std::integral_constant<int, 0>{});
+    __syncthreads();
+    multiply(0);
+  }
+
+  // ---- epilogue straight from the accumulators: lane (column r32, row group kb) holds rows (r & 3) + 8 (r >> 2) + 4 kb
+  const float* __restrict__ bias = job.bias;
+  const int gc = col0 + wn * 32 + r32;
+  if (gc < N) {
+    const float bcol = bias ? bias[gc] : 0.f;
+    const float b2 = job.row_flag ? job.bias2[gc] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gr = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+      if (gr < M) {
+        float v = acc[r] + (acs[r] + act[r] * (1.f / 2048.f)) * (1.f / 2048.f) + bcol;
+        if (job.row_flag && job.row_flag[gr]) v += b2;
+        if (job.relu) v = fmaxf(v, 0.f);
+        y[(size_t)gr * job.ldy + gc] = gr < live ? out_word(v, job.out_fmt) : 0.f;
+      }
+    }
+  }
+}
+
 // ---- LayerNorm over the concatenation of up to two column segments, one wave per row, eps 1e-5,
 // biased variance (torch.nn.LayerNorm); width <= 512, multiple of 64 per segment.
 __global__ __launch_bounds__(256) void layernorm_seg_kernel(float* __restrict__ out, int ldo,
@@ -491,10 +655,21 @@ extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
     tiles64 += (long long)((job.M + BM - 1) / BM) * ((job.N + 63) / 64);
   }
   const int bn = tiles64 >= 200 ? 64 : 32;
+  // the 64 x 128-tile form for launches with thousands of rows (a batch of streams: 10-20 % faster there, profiles/
+  // r04_gemm_wide_tiles.txt); at one stream's ~1 k rows it has at most 288 tiles and measured no faster (q|k|v 19.0 vs 18.9 us)
+  // or slower (fc1 17.3 vs 12.6 us: 120 tiles leave half the chip idle), so the switch-over sits above those
+  long long tiles_wide = 0;
+  for (int j = 0; j < args->num_jobs; ++j)
+    tiles_wide += (long long)((args->job[j].M + kWM - 1) / kWM) * ((args->job[j].N + kWN - 1) / kWN);
+  static const long long wide_min = getenv("SIMPB_GEMM_WIDE_MIN_TILES") ? atoll(getenv("SIMPB_GEMM_WIDE_MIN_TILES")) : 400;   // (env: measurement only)
+  const bool wide_tiles = split && tiles_wide >= wide_min;
   long long total = 0;
   for (int j = 0; j < args->num_jobs; ++j) {
     L.tile_start[j] = (int)total;
-    total += (long long)((args->job[j].M + BM - 1) / BM) * ((args->job[j].N + bn - 1) / bn);
+    if (wide_tiles)
+      total += (long long)((args->job[j].M + kWM - 1) / kWM) * ((args->job[j].N + kWN - 1) / kWN);
+    else
+      total += (long long)((args->job[j].M + BM - 1) / BM) * ((args->job[j].N + bn - 1) / bn);
   }
   if (total > (1 << 24)) return SIMPB_EINVAL;
   for (int j = args->num_jobs; j <= SIMPB_GEMM_MAX_JOBS; ++j) L.tile_start[j] = (int)total;
@@ -502,7 +677,9 @@ extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
   (void)hipGetLastError();
   dim3 grid(L.per_xcd * 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (split && bn == 64)
+  if (wide_tiles)
+    hipLaunchKernelGGL((gemm_f16x3_wide_kernel<2>), grid, dim3(kThreads), 0, s, L);
+  else if (split && bn == 64)
     hipLaunchKernelGGL((gemm_f16x3_kernel<64, 2, 64>), grid, dim3(kThreads), 0, s, L);
   else if (split)
     hipLaunchKernelGGL((gemm_f16x3_kernel<32, 2, 128>), grid, dim3(kThreads), 0, s, L);

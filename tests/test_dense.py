@@ -159,6 +159,49 @@ def test_gemm_grouped_strided_and_m_live():
 
 
 @gpu
+@pytest.mark.parametrize("m,n,ks,relu", [
+    (2250, 1536, [256, 256], False),      # q|k|v of two streams' 2D sets: 36 x 12 tiles of 64 x 128, partial last row tile
+    (3300, 1000, [512], True),            # N not a multiple of the tile: partial column tiles
+    (14405, 256, [1024, 512], True),      # a batch of streams: narrow output, many row tiles, two segments, K = 1536
+    (2700, 1536, [128, 128, 128, 128], False),   # four segments
+])
+def test_gemm_wide_tiles_vs_float64(m, n, ks, relu):
+    """Launches with >= 400 tiles of 64 x 128 take csrc/gemm.hip gemm_f16x3_wide_kernel (one 32 x 32 tile per wave over the
+    whole K, accumulators straight to memory): same bound against float64 as the other forms."""
+    _gemm_vs_float64(m, n, ks, relu, True)
+
+
+@gpu
+def test_gemm_wide_tiles_m_live_row_flag_and_split_halfs_output():
+    """The wide-tile form with everything a decoder launch asks of it: a device-side live row count (rows past it come back
+    as zeros, a tile made of capacity rows only does no work), the flagged second bias, and the (hi, lo) half-pair output
+    format of the attention projections -- against the narrow-tile form on the same operands (forced by a launch too
+    small for the wide one: the same rows as a 512-row problem)."""
+    from simpb_amd.plugin import routes
+    g = torch.Generator().manual_seed(31)
+    m, n, k, live_n = 3072, 1536, 512, 2260
+    x = torch.randn(1, m, k, generator=g).cuda()
+    w = (torch.randn(n, k, generator=g) / 22).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    b2 = torch.randn(n, generator=g).cuda()
+    flag = (torch.rand(m, generator=g) > 0.5).to(torch.int32).cuda()
+    live = torch.tensor([live_n], dtype=torch.int32, device="cuda")
+    want = x[0, :live_n].cpu().double() @ w.cpu().double().t() + b.cpu().double() + flag[:live_n].cpu().double()[:, None] * b2.cpu().double()
+    got = dense.linear(x, w, b, m_live=live, row_flag=flag, bias2=b2)
+    assert float((got[0, :live_n].cpu().double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert bool((got[0, live_n:] == 0).all())
+    halfs = dense.linear(x, w, b, m_live=live, row_flag=flag, bias2=b2, split_halfs=True)
+    bits = halfs[0, :live_n].view(torch.int32)
+    hi = (bits & 0xFFFF).to(torch.int16).view(torch.float16).float()
+    lo = ((bits >> 16) & 0xFFFF).to(torch.int16).view(torch.float16).float()
+    assert float((hi + lo / 2048.0 - got[0, :live_n]).abs().max()) <= 2e-6 * float(got.abs().max())
+    assert bool((halfs[0, live_n:].view(torch.int32) == 0).all())
+    # the narrow-tile kernel on a slice small enough to miss the wide form: same numbers up to summation order
+    part = dense.linear(x[:, :512], w, b, row_flag=flag[:512].contiguous(), bias2=b2)
+    assert float((part[0] - got[0, :512]).abs().max()) <= 2e-5 * float(got.abs().max())
+
+
+@gpu
 def test_gemm_rejects_bad_layouts():
     x = torch.randn(8, 96, device="cuda")      # K not a multiple of 64
     with pytest.raises(RuntimeError):

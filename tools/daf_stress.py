@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--launches", type=int, default=3000)
     ap.add_argument("--cu-split", type=int, default=0)
     ap.add_argument("--anchors", type=int, default=900)
+    ap.add_argument("--victim", default="daf",
+                    help="the kernel that is re-launched and compared bit for bit with its idle-device output: daf (default), or one "
+                         "of the decoder's dense kernels that keep packed-FP32 instructions: layernorm | attention | chain | gemm")
     ap.add_argument("--build-flags", default="",
                     help="extra hipcc flags for a variant build of the whole library (e.g. -fno-slp-vectorize: no packed-FP32 "
                          "instructions in the victim kernel), combined with --k16 when both are given")
@@ -53,6 +56,32 @@ def main():
 
     def daf():
         return ops.deformable_aggregation_function(col, ss32, ssi32, loc, w)
+
+    if args.victim != "daf":
+        # the decoder's dense kernels whose files are NOT built with NO_PACKED_FP32 (simpb_amd/build.py): row statistics of the
+        # LayerNorm (csrc/gemm.hip), the softmax of the attention kernels, the chain kernel's LayerNorm / post stages, the GEMM epilogue
+        from simpb_amd.plugin import dense, fused
+        victim_x = torch.randn(1, 900, 512, generator=g).cuda()   # (its own name: `vx` below is a co-runner operand)
+        if args.victim == "layernorm":
+            ln = torch.nn.LayerNorm(512).cuda()
+            daf = lambda: dense.layernorm([victim_x[..., :256], victim_x[..., 256:]], ln)   # noqa: E731
+        elif args.victim == "attention":
+            qkv = torch.randn(1, 900, 1536, generator=g).cuda()
+            daf = lambda: ops.attention_f32(qkv[..., :512], qkv[..., 512:1024], qkv[..., 1024:], 8, split=1)   # noqa: E731
+        elif args.victim == "gemm":
+            gw_ = (torch.randn(256, 512, generator=g) / 22).cuda()
+            gb_ = torch.randn(256, generator=g).cuda()
+            daf = lambda: dense.linear(victim_x, gw_, gb_, relu=True)   # noqa: E731
+        elif args.victim == "chain":
+            from simpb_amd.plugin.detection3d import SparseBox3DEncoder
+            from simpb_amd import synth
+            enc = SparseBox3DEncoder(embed_dims=[128, 32, 32, 64], vel_dims=3, mode="cat", output_fc=False, in_loops=1, out_loops=4)
+            synth.load_procedural(enc, seed=3)
+            enc = enc.cuda()
+            box = torch.randn(1, 900, 11, generator=g).cuda()
+            daf = lambda: enc(box)   # noqa: E731
+        else:
+            raise SystemExit("unknown --victim")
 
     ref = daf()
     torch.cuda.synchronize()
@@ -164,11 +193,12 @@ def main():
             rows = d.any(-1).sum()
             bad_rows += rows
             bad_launch += (rows > 0).long()
-            blocks += d.reshape(-1, 4, 64).any(-1).sum(0)
+            if d.shape[-1] % 256 == 0:
+                blocks += d.reshape(-1, 4, d.shape[-1] // 4).any(-1).sum(0)
         if it % 200 == 199:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
-    print(f"co={args.co} fp16_matrix_step={'1 x 32x32x16' if args.k16 else '2 x 32x32x8'} cu_split={args.cu_split}: {int(bad_launch)} faulty launches of {args.launches}, "
+    print(f"victim={args.victim} co={args.co} fp16_matrix_step={'1 x 32x32x16' if args.k16 else '2 x 32x32x8'} cu_split={args.cu_split}: {int(bad_launch)} faulty launches of {args.launches}, "
           f"{int(bad_rows)} rows; faulty rows by channel block [0-63, 64-127, 128-191, 192-255]: {blocks.tolist()}", flush=True)
 
 
