@@ -61,6 +61,17 @@ def parse():
     ap.add_argument("--h2d", action="store_true",
                     help="frames start in pinned host memory and cross PCIe inside the timed step (async copy on the backbone "
                          "stream, beside the previous frame's decoder); default: inputs resident in HBM, as `value` requires")
+    ap.add_argument("--token-std", type=float, default=None,
+                    help="synthetic-weight conditioning for configurations other than the default: rescale the FPN's output "
+                         "convolutions (linear in their weights and biases) so that the camera tokens have this standard deviation. "
+                         "A random-weight ResNet101 leaves tokens an order of magnitude larger than the ResNet50's, which drives the "
+                         "refined anchors out of view (V = 2 252 valid triples instead of ~12.9 k): with the R50's token scale "
+                         "(reported as config.token_std) the decoder sits at the operating point SURVEY.md 8d describes")
+    ap.add_argument("--residual-damp", type=float, default=1.0,
+                    help="synthetic-weight conditioning for deep backbones: scale the last BatchNorm (gain and bias) of every "
+                         "bottleneck's residual branch. He-initialised random weights let the activations of a ResNet101 grow by a "
+                         "factor per block until the fp16 maps overflow (tokens NaN at 33 blocks; round 3's R101 line ran on those); "
+                         "the default workload (ResNet50, 16 blocks) stays as it is")
     ap.add_argument("--h2d-steps", type=int, default=30,
                     help="steps of the secondary leg that repeats the measurement with the frames crossing PCIe (the reference's "
                          "protocol); reported as reference_protocol_h2d, never as value; 0 = skip")
@@ -206,9 +217,25 @@ def build_model(args, device):
     cfg = configs.simpb_plus(depth=args.depth, input_shape=tuple(args.image_wh), anchor=synth.anchors(900))
     model = plugin.build_detector(cfg["model"]).eval()
     synth.load_procedural(model)
+    if args.residual_damp != 1.0:   # synthetic-weight conditioning (see --residual-damp): the last BatchNorm of every bottleneck
+        with torch.no_grad():
+            for m in model.img_backbone.modules():
+                if hasattr(m, "bn3") and hasattr(m, "conv3"):
+                    m.bn3.weight.mul_(args.residual_damp)
+                    m.bn3.bias.mul_(args.residual_damp)
     model.to(device)
     model.fuse_conv_bn()  # the reference's own --fuse-conv-bn inference option (tools/benchmark.py:76-78)
     model.half_backbone()  # fp16 backbone+FPN, fp32 head: the reference's own precision split (config :26)
+    with torch.no_grad():
+        img = synth.images(args.bs, 0, tuple(args.image_wh)).to(device)
+        std = float(model.extract_feat(img)[0].float().std())
+        if args.token_std:
+            for m in model.img_neck.fpn_convs:
+                m.conv.weight.mul_(args.token_std / std)
+                if m.conv.bias is not None:
+                    m.conv.bias.mul_(args.token_std / std)
+            std = float(model.extract_feat(img)[0].float().std())
+    model.simpb_token_std = std
     return model
 
 
@@ -507,7 +534,8 @@ def main():
                                    f"{args.streams} stream(s) x bs={args.bs} per GPU, temporal",
                        "streams_per_gpu": args.bs * args.streams, "batch_semantics": ("one stream" if args.bs == 1 else "reference batch (groups padded to the max over the batch)" if args.reference_batch else f"{args.bs} independent streams per launch, each decoded as a batch of one (SURVEY.md 8e)"), "backbone_dtype": "f16 (backbone+FPN only, the reference's own fp16 split: config :26, simpb.py:63)", "head_dtype": head_dtype_note(), "parallelism": f"stream-sharded x{world}, RCCL all-gather of detections"
                        if world > 1 else "single GPU", "inputs": "pinned host frames, H2D inside the timed step" if args.h2d else "resident in HBM",
-                       "fp16_matrix_step": "2 x v_mfma_f32_32x32x8f16 (csrc/mfma_f16.h)", "num_query2d_last_frame": n2, "frame_runner": mode},
+                       "fp16_matrix_step": "2 x v_mfma_f32_32x32x8f16 (csrc/mfma_f16.h)", "num_query2d_last_frame": n2, "frame_runner": mode,
+                       "token_std": getattr(runner.model, "simpb_token_std", None)},
             "roofline": roof, "roofline_msda": roof2, "reference_protocol_h2d": h2d_leg,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -5,7 +5,10 @@ import csv
 import json
 import sys
 
-NAMES = {"gemm_f32_kernel<64": "gemm_f32_kernel<64,4,64>", "gemm_f32_kernel<32, 2": "gemm_f32_kernel<32,2,128>",
+NAMES = {"gemm_f16x3_wide_kernel": "gemm_f16x3_wide_kernel (64x128 tiles)", "gemm_f16x3_kernel<64": "gemm_f16x3_kernel<64,2,64> (split operands)",
+         "gemm_f16x3_kernel<32": "gemm_f16x3_kernel<32,2,128> (split operands)", "attention_halfs_kernel<false": "attention_halfs_kernel<false> (split operands)",
+         "attention_halfs_kernel<true": "attention_halfs_kernel<true> (split operands, grouped)",
+         "gemm_f32_kernel<64": "gemm_f32_kernel<64,4,64>", "gemm_f32_kernel<32, 2": "gemm_f32_kernel<32,2,128>",
          "gemm_f32_kernel<32, 4": "gemm_f32_kernel<32,4,64>", "attention_f32_kernel<false": "attention_f32_kernel<false>",
          "attention_f32_kernel<true": "attention_f32_kernel<true>", "mlp_chain_mfma": "mlp_chain_mfma_kernel",
          "mlp_chain_r4": "mlp_chain_r4_kernel", "mlp_chain_r32": "mlp_chain_r32_kernel", "linear_f32_mfma": "linear_f32_mfma", "linear_f16x3": "linear_f16x3 (value_proj)",

@@ -19,6 +19,7 @@ import sys
 
 KERNELS = {"daf_fwd_rows": "daf_fwd_rows", "msda_grouped_fwd": "msda_grouped_fwd", "conv1x1_f16_kernel": "conv1x1_f16",
            "linear_f16x3_kernel": "linear_f16x3", "format_tokens_kernel": "format_tokens", "mlp_chain_mfma_kernel": "mlp_chain_mfma",
+           "gemm_f16x3_wide_kernel": "gemm_f16x3_wide", "gemm_f16x3_kernel": "gemm_f16x3", "attention_halfs_kernel": "attention_halfs",
            "gemm_f32_kernel": "gemm_f32", "attention_f32_kernel": "attention_f32", "mlp_chain_r4_kernel": "mlp_chain_r4",
            "conv_staged_kernel": "conv_staged (3x3 / 1x1)", "conv3x3_f16_kernel": "conv3x3 direct", "linear_h2_kernel": "linear_h2 (value_proj)",
            "alloc_static_kernel": "alloc_static", "daf_fused_rows": "daf_fused_rows", "msda_linear_fwd": "msda_linear_fwd",

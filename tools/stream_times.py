@@ -40,6 +40,11 @@ if REF_BATCH:
     sys.argv.remove("--reference-batch")
 r = PipelinedRunner(model, BS, (wh[1], wh[0]), capacity=1536 if BS == 1 or not REF_BATCH else 2048, device=torch.device("cuda"),
                     independent_streams=not REF_BATCH)
+XCD_DROP = 0
+if "--bb-xcd-drop" in sys.argv:   # --bb-xcd-drop K: the backbone stream loses K whole XCDs (CU mask bit i belongs to XCD i % 8); the decoder keeps the chip
+    i = sys.argv.index("--bb-xcd-drop")
+    XCD_DROP = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 DEC_ONLY = "--dec-only" in sys.argv   # for rocprofv3 --kernel-trace: decoder graph replays with nothing beside them
 if len(sys.argv) > 1 and not DEC_ONLY and "--bb-only" not in sys.argv and "--co" not in sys.argv and "--prio" not in sys.argv:
     # --bb-drop N: the backbone stream loses one group of 8 CUs in every N groups (in every XCD, whichever way CU indices
@@ -59,6 +64,21 @@ if len(sys.argv) > 1 and not DEC_ONLY and "--bb-only" not in sys.argv and "--co"
     assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), m) == 0
     r.s_bb = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", 0))
     print(f"backbone stream on {kept} of {n_cu} CUs", flush=True)
+if XCD_DROP:
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (n_cu + 31) // 32
+    m = (ctypes.c_uint32 * words)()
+    kept = 0
+    for i in range(n_cu):
+        if i % 8 >= XCD_DROP:
+            m[i // 32] |= 1 << (i % 32)
+            kept += 1
+    h = ctypes.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), m) == 0
+    r.s_bb = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", 0))
+    print(f"backbone stream on {kept} of {n_cu} CUs ({XCD_DROP} XCD(s) left to the decoder alone)", flush=True)
 imgs = [synth.images(BS, f, wh).cuda() for f in range(4)]
 metas = [synth.frame_metas(BS, f, wh) for f in range(60)]
 for f in range(24):
