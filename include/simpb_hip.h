@@ -442,6 +442,16 @@ int simpb_bank_cache(float* confidence, float* cached_feature, float* cached_anc
                      const float* cls, int batch_size, int num_anchors, int num_classes, int num_temp, int embed_dims,
                      int has_previous, float confidence_decay, int has_threshold, float threshold, const int* hold,
                      int num_hold, int* sticky, void* stream);
+/* simpb_bank_cache with one workgroup per stream (a batch of streams: the serial form walks them, 13 us each). Same
+ * arguments and results; sync_words: two persistent u32 words in device memory, zero before the first call and owned by
+ * these calls from then on (an arrival counter and a launch count: the workgroups meet once between counting the fresh
+ * instances of the streams in front of them and rewriting their own instance_id). batch_size <= 64; NULL sync_words or a
+ * batch of one: the serial kernel. */
+int simpb_bank_cache_streams(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
+                             long long* prev_id, long long* ids_out, int* index_scratch, const float* feature, const float* anchor,
+                             const float* cls, int batch_size, int num_anchors, int num_classes, int num_temp, int embed_dims,
+                             int has_previous, float confidence_decay, int has_threshold, float threshold, const int* hold,
+                             int num_hold, int* sticky, unsigned* sync_words, void* stream);
 
 /* Fixed-shape detection records of SparseBox3DDecoder.decode_with2d (models/detection3d/decoder.py:124-252).
  * 3D (:133-167 with squeezed classes + decode_box :23-34), one workgroup per sample:

@@ -46,6 +46,7 @@ SIGNATURES = {
     "simpb_bank_update_rank": ([_P, _P] + [_I] * 4 + [_P], _I),
     "simpb_bank_update_merge": ([_P] * 13 + [_I, _P] + [_I] * 5 + [_P], _I),
     "simpb_bank_cache": ([_P] * 10 + [_I] * 6 + [_F, _I, _F, _P, _I, _P, _P], _I),
+    "simpb_bank_cache_streams": ([_P] * 10 + [_I] * 6 + [_F, _I, _F, _P, _I, _P, _P, _P], _I),
     "simpb_decode3d_record": ([_P] * 6 + [_I] * 4 + [_P], _I),
     "simpb_decode2d_record": ([_P] * 6 + [_I] * 4 + [_F] * 4 + [_P], _I),
     "simpb_record2d_compact": ([_P, _LL, _P, _LL, _I, _I, _I, _P], _I),

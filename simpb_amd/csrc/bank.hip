@@ -239,6 +239,117 @@ __global__ __launch_bounds__(512) void bank_cache_kernel(float* __restrict__ con
   if (tid == 0) *prev_id = next_id;
 }
 
+// ---- the same commit with ONE WORKGROUP PER STREAM (a batch of streams: the serial walk above is 13 us per stream, 107 us at
+// eight). Fresh track ids are numbered over the flattened batch (:179-181), so stream b's first fresh id is prev_id + the
+// number of fresh instances of the streams in front of it: every workgroup counts those itself (ids < 0 and, with a
+// threshold, score >= threshold: a few thousand loads), which needs the OTHER streams' instance_id as the frame found them
+// -- and every stream rewrites its own instance_id below. So between "counted" and "rewrite" the workgroups meet once:
+// an arrival counter in device memory (sync[0], never reset: launch e waits for (e + 1) * bs arrivals, e = sync[1], which
+// workgroup 0 advances behind the meeting). All bs workgroups are resident at once (bs <= 64 workgroups of 512 threads on 256
+// CUs), every one of them arrives before it waits, and the wait is bounded (a launch that could not be co-scheduled would
+// fall through after ~2^22 polls instead of hanging). prev_id is read by everyone in front of the meeting and written by the
+// last stream's workgroup behind it.
+__global__ __launch_bounds__(512) void bank_cache_streams_kernel(float* __restrict__ conf, int* __restrict__ index,
+                                                                 long long* __restrict__ ids_out,
+                                                                 long long* __restrict__ instance_id,
+                                                                 long long* __restrict__ prev_id, const float* __restrict__ cls,
+                                                                 int bs, int A, int C, int T, int has_prev, float decay,
+                                                                 int has_threshold, float threshold,
+                                                                 const int* __restrict__ hold, int num_hold,
+                                                                 int* __restrict__ sticky, unsigned* __restrict__ sync) {
+  __shared__ unsigned long long key[kCap];
+  __shared__ long long ids[kCap];
+  __shared__ int scan[kCap];
+  __shared__ float fresh_score[kCap];
+  __shared__ int s_red[8];
+  __shared__ int s_front;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const bool hold_back = held(hold, num_hold, sticky);
+  if (sticky) {
+    __syncthreads();
+    if (tid == 0) *sticky = hold_back ? 1 : 0;   // (every workgroup writes the same verdict: a set word stays set, see held())
+  }
+  if (hold_back) return;  // uniform over the whole launch: nobody arrives, the counters stay where they are
+  const long long first_id = *prev_id;
+  const unsigned epoch = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // fresh instances of the streams in front of this one
+  int mine = 0;
+  for (int i = tid; i < b * A; i += 512) {
+    const long long id = instance_id ? instance_id[i] : -1;
+    if (id < 0 && (!has_threshold || sigmoidf(row_max(cls + (size_t)i * C, C)) >= threshold)) ++mine;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m);
+  if ((tid & 63) == 0) s_red[tid >> 6] = mine;
+  // this stream's scores and ranking (as the serial kernel)
+  for (int a = tid; a < kCap; a += 512) {
+    unsigned long long kv = 0ull;
+    if (a < A) {
+      const float s = sigmoidf(row_max(cls + ((size_t)b * A + a) * C, C));
+      fresh_score[a] = s;
+      float sc = s;
+      if (has_prev && a < T) sc = fmaxf(conf[(size_t)b * T + a] * decay, s);
+      kv = sort_key(sc, (unsigned)a);
+    }
+    key[a] = kv;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int f = 0;
+    for (int w = 0; w < 8; ++w) f += s_red[w];
+    s_front = f;
+  }
+  bitonic_desc(key, tid);
+  for (int a = tid; a < kCap; a += 512) {
+    long long id = -1;
+    int fresh = 0;
+    if (a < A) {
+      id = instance_id ? instance_id[(size_t)b * A + a] : -1;
+      fresh = id < 0 && (!has_threshold || fresh_score[a] >= threshold);
+    }
+    ids[a] = id;
+    scan[a] = fresh;
+  }
+  __syncthreads();
+  for (int off = 1; off < kCap; off <<= 1) {
+    const int a0 = tid, a1 = tid + 512;
+    const int v0 = a0 >= off ? scan[a0 - off] : 0, v1 = scan[a1 - off];
+    __syncthreads();
+    scan[a0] += v0;
+    scan[a1] += v1;
+    __syncthreads();
+  }
+  const int total = scan[kCap - 1];
+  const long long next_id = first_id + s_front;
+  for (int a = tid; a < A; a += 512) {
+    const int inc = scan[a], prev = a ? scan[a - 1] : 0;
+    if (inc != prev) ids[a] = next_id + (inc - 1);
+  }
+  __syncthreads();
+  // ---- the meeting: every stream has read what it needs of the others' instance_id and of prev_id
+  if (tid == 0) {
+    __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = (epoch + 1u) * (unsigned)bs;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      if ((int)(__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < T; r += 512) {
+    conf[(size_t)b * T + r] = key_value(key[r]);
+    index[(size_t)b * T + r] = (int)key_index(key[r]);
+  }
+  for (int a = tid; a < A; a += 512) {
+    ids_out[(size_t)b * A + a] = ids[a];
+    if (instance_id) instance_id[(size_t)b * A + a] = a < T ? ids[key_index(key[a])] : -1;  // :191-195
+  }
+  if (tid == 0) {
+    if (b == bs - 1) *prev_id = next_id + total;
+    if (b == 0) __hip_atomic_store(&sync[1], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- cache: kept rows of the feature / anchor tables into the persistent state, one wave per row
 __global__ __launch_bounds__(64) void bank_gather_kernel(float* __restrict__ out_f, float* __restrict__ out_a,
                                                          const float* __restrict__ src_f, const float* __restrict__ src_a,
@@ -310,11 +421,11 @@ extern "C" int simpb_bank_update(float* feature_out, float* anchor_out, long lon
                                  num_temp, embed_dims, 0, stream);
 }
 
-extern "C" int simpb_bank_cache(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
-                                long long* prev_id, long long* ids_out, int* index_scratch, const float* feature,
-                                const float* anchor, const float* cls, int batch_size, int num_anchors, int num_classes,
-                                int num_temp, int embed_dims, int has_previous, float confidence_decay, int has_threshold,
-                                float threshold, const int* hold, int num_hold, int* sticky, void* stream) {
+static int bank_cache_launch(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
+                             long long* prev_id, long long* ids_out, int* index_scratch, const float* feature,
+                             const float* anchor, const float* cls, int batch_size, int num_anchors, int num_classes,
+                             int num_temp, int embed_dims, int has_previous, float confidence_decay, int has_threshold,
+                             float threshold, const int* hold, int num_hold, int* sticky, unsigned* sync, void* stream) {
   if (!confidence || !cached_feature || !cached_anchor || !prev_id || !ids_out || !index_scratch || !feature || !anchor ||
       !cls || batch_size <= 0 || num_anchors <= 0 || num_anchors > kCap || num_classes <= 0 || num_temp <= 0 ||
       num_temp > num_anchors || embed_dims <= 0 || (embed_dims & 3) || batch_size > 65535 || num_hold < 0 ||
@@ -322,10 +433,36 @@ extern "C" int simpb_bank_cache(float* confidence, float* cached_feature, float*
     return SIMPB_EINVAL;
   (void)hipGetLastError();
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(bank_cache_kernel, dim3(1), dim3(512), 0, s, confidence, index_scratch, ids_out, instance_id, prev_id, cls,
-                     batch_size, num_anchors, num_classes, num_temp, has_previous, confidence_decay, has_threshold, threshold, hold,
-                     num_hold, sticky);
+  if (sync && batch_size > 1 && batch_size <= 64)
+    hipLaunchKernelGGL(bank_cache_streams_kernel, dim3(batch_size), dim3(512), 0, s, confidence, index_scratch, ids_out, instance_id,
+                       prev_id, cls, batch_size, num_anchors, num_classes, num_temp, has_previous, confidence_decay, has_threshold,
+                       threshold, hold, num_hold, sticky, sync);
+  else
+    hipLaunchKernelGGL(bank_cache_kernel, dim3(1), dim3(512), 0, s, confidence, index_scratch, ids_out, instance_id, prev_id, cls,
+                       batch_size, num_anchors, num_classes, num_temp, has_previous, confidence_decay, has_threshold, threshold, hold,
+                       num_hold, sticky);
   hipLaunchKernelGGL(bank_gather_kernel, dim3(num_temp, batch_size), dim3(64), 0, s, cached_feature, cached_anchor, feature,
                      anchor, index_scratch, num_anchors, num_temp, embed_dims, hold, num_hold, sticky);
   return simpb_check_launch();
+}
+
+extern "C" int simpb_bank_cache(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
+                                long long* prev_id, long long* ids_out, int* index_scratch, const float* feature,
+                                const float* anchor, const float* cls, int batch_size, int num_anchors, int num_classes,
+                                int num_temp, int embed_dims, int has_previous, float confidence_decay, int has_threshold,
+                                float threshold, const int* hold, int num_hold, int* sticky, void* stream) {
+  return bank_cache_launch(confidence, cached_feature, cached_anchor, instance_id, prev_id, ids_out, index_scratch, feature, anchor,
+                           cls, batch_size, num_anchors, num_classes, num_temp, embed_dims, has_previous, confidence_decay,
+                           has_threshold, threshold, hold, num_hold, sticky, nullptr, stream);
+}
+
+extern "C" int simpb_bank_cache_streams(float* confidence, float* cached_feature, float* cached_anchor, long long* instance_id,
+                                        long long* prev_id, long long* ids_out, int* index_scratch, const float* feature,
+                                        const float* anchor, const float* cls, int batch_size, int num_anchors, int num_classes,
+                                        int num_temp, int embed_dims, int has_previous, float confidence_decay,
+                                        int has_threshold, float threshold, const int* hold, int num_hold, int* sticky,
+                                        unsigned* sync_words, void* stream) {
+  return bank_cache_launch(confidence, cached_feature, cached_anchor, instance_id, prev_id, ids_out, index_scratch, feature, anchor,
+                           cls, batch_size, num_anchors, num_classes, num_temp, embed_dims, has_previous, confidence_decay,
+                           has_threshold, threshold, hold, num_hold, sticky, sync_words, stream);
 }

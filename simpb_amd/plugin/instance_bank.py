@@ -100,6 +100,8 @@ class InstanceBank(nn.Module):
             instance_id=torch.full((batch_size, n), -1, dtype=torch.long, device=device),
             prev_id=torch.zeros((), dtype=torch.long, device=device),
         )
+        # two words the per-stream commit kernel (csrc/bank.hip bank_cache_streams_kernel) meets on; not part of the bank's state
+        self._sync = torch.zeros(2, dtype=torch.int32, device=device)
         self.reset()
 
     def _keep(self, name, value):
@@ -275,13 +277,15 @@ class InstanceBank(nn.Module):
         ids_out = torch.empty(bs, a, dtype=torch.long, device=cls.device)
         scratch = torch.empty(bs, t, dtype=torch.int32, device=cls.device)
         has_prev = self.confidence is not None
-        _lib.check(_lib.lib().simpb_bank_cache(
+        # a batch of streams: one workgroup per stream (they meet once inside the launch); a batch of one: the serial kernel
+        sync = self._sync if (bs > 1 and routes.R.bank_cache_per_stream and getattr(self, "_sync", None) is not None) else None
+        _lib.check(_lib.lib().simpb_bank_cache_streams(
             _ptr(st["confidence"]), _ptr(st["cached_feature"]), _ptr(st["cached_anchor"]), _ptr(st["instance_id"]),
             _ptr(st["prev_id"]), _ptr(ids_out), _ptr(scratch), _ptr(instance_feature.detach().contiguous().float()),
             _ptr(anchor.detach().contiguous().float()), _ptr(cls), bs, a, cls.shape[-1], t, c, 1 if has_prev else 0,
             float(self.confidence_decay), 0 if threshold is None else 1, 0.0 if threshold is None else float(threshold),
             _ptr(hold) if hold is not None else None, 0 if hold is None else hold.numel(),
-            _ptr(sticky) if sticky is not None else None, _stream()), "simpb_bank_cache")
+            _ptr(sticky) if sticky is not None else None, _ptr(sync) if sync is not None else None, _stream()), "simpb_bank_cache")
         self.metas = metas
         self.confidence, self.cached_feature, self.cached_anchor = st["confidence"], st["cached_feature"], st["cached_anchor"]
         self.instance_id, self.prev_id = st["instance_id"], st["prev_id"]

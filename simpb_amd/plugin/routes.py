@@ -42,6 +42,9 @@ DEFAULTS = dict(
     fused_decode=True,
     # InstanceBank on its persistent state through csrc/bank.hip. False: the PyTorch statement of instance_bank.py.
     fused_bank=True,
+    # ... its frame-end commit with one workgroup per stream for a batch of streams (they meet once inside the launch on an
+    # arrival counter: csrc/bank.hip bank_cache_streams_kernel). False: one workgroup walks the streams (13 us each).
+    bank_cache_per_stream=True,
     # fork the value branch of an attention operator onto a side stream (measured slower inside a replayed graph)
     parallel_branches=False,
     # own 1x1 / 3x3 convolutions and stem epilogue (csrc/conv1x1.hip, conv3x3.hip, bias_act.hip). False: vendor

@@ -701,3 +701,42 @@ def test_norm_inside_the_refinement_launch_equals_norm_then_head(live):
         assert float((ref2.norm_out - xn).abs().max()) <= 1e-5
         if live is not None:
             assert float(ref2.norm_out[:, live:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("bs,threshold", [(8, None), (8, 0.3), (3, 0.3), (17, None)])
+def test_bank_cache_one_workgroup_per_stream_equals_the_serial_walk(bs, threshold):
+    """simpb_bank_cache_streams (csrc/bank.hip bank_cache_streams_kernel: one workgroup per stream, fresh ids offset by the
+    counts of the streams in front, one meeting inside the launch) against the serial kernel on the same state: kept
+    confidences / rows / ids, the ids of all instances and prev_id, bit for bit, over three consecutive commits (the
+    second and third start from ids the first left, with a partly tracked bank)."""
+    from simpb_amd import _lib
+    from simpb_amd.plugin.ops import _ptr, _stream
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(100 + bs)
+    A, T, C, E = 900, 600, 10, 256
+
+    def fresh_state():
+        return dict(conf=torch.rand(bs, T, generator=g).cuda(), cf=torch.zeros(bs, T, E).cuda(), ca=torch.zeros(bs, T, 11).cuda(),
+                    iid=torch.full((bs, A), -1, dtype=torch.long).cuda(), prev=torch.zeros((), dtype=torch.long).cuda())
+
+    base = fresh_state()
+    states = [dict((k, v.clone()) for k, v in base.items()) for _ in range(2)]
+    sync = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for step in range(3):
+        feat = torch.randn(bs, A, E, generator=g).cuda()
+        anchor = torch.randn(bs, A, 11, generator=g).cuda()
+        cls = (torch.randn(bs, A, C, generator=g) * 2).cuda()
+        outs = []
+        for which, st in enumerate(states):
+            ids_out = torch.empty(bs, A, dtype=torch.long, device="cuda")
+            scratch = torch.empty(bs, T, dtype=torch.int32, device="cuda")
+            _lib.check(lib.simpb_bank_cache_streams(
+                _ptr(st["conf"]), _ptr(st["cf"]), _ptr(st["ca"]), _ptr(st["iid"]), _ptr(st["prev"]), _ptr(ids_out), _ptr(scratch),
+                _ptr(feat), _ptr(anchor), _ptr(cls), bs, A, C, T, E, 1 if step else 0, 0.6, 0 if threshold is None else 1,
+                0.0 if threshold is None else threshold, None, 0, None, _ptr(sync) if which == 1 else None, _stream()), "bank_cache")
+            outs.append(ids_out)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]), step
+        for k in ("conf", "cf", "ca", "iid", "prev"):
+            assert torch.equal(states[0][k], states[1][k]), (step, k)
+        assert int(states[1]["prev"]) > 0 and int(sync[1]) == step + 1 and int(sync[0]) == (step + 1) * bs
