@@ -15,7 +15,7 @@ template <int V>
 __global__ __launch_bounds__(256) void burn(float* sink, int iters) {
   const float seed = (float)(threadIdx.x & 7) * 0.125f;
   f16v acc = {0};
-  f4v acc4 = {0, 0, 0, 0};
+  f4v acc4 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0}, q2 = {0, 0, 0, 0}, q3 = {0, 0, 0, 0};
   h8 a8, c8;
   h4 a4, c4;
   b8 ab, cb;
@@ -29,7 +29,33 @@ __global__ __launch_bounds__(256) void burn(float* sink, int iters) {
     if constexpr (V == 4) acc = __builtin_amdgcn_mfma_f32_32x32x8f16(a4, c4, acc, 0, 0, 0);
     if constexpr (V == 5) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 0.5f, acc, 0, 0, 0);
     if constexpr (V == 6) acc4 = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, c4, acc4, 0, 0, 0);
+    // the small-tile instructions of csrc/mlp_chain.hip, four independent accumulators each (throughput, not latency)
+    if constexpr (V == 7) {
+      acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(seed, 0.5f, acc4, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f32_4x4x1f32(seed, 0.25f, q1, 0, 0, 0);
+      q2 = __builtin_amdgcn_mfma_f32_4x4x1f32(seed, 0.125f, q2, 0, 0, 0);
+      q3 = __builtin_amdgcn_mfma_f32_4x4x1f32(seed, 0.75f, q3, 0, 0, 0);
+    }
+    if constexpr (V == 8) {
+      acc4 = __builtin_amdgcn_mfma_f32_4x4x4f16(a4, c4, acc4, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f32_4x4x4f16(c4, a4, q1, 0, 0, 0);
+      q2 = __builtin_amdgcn_mfma_f32_4x4x4f16(a4, a4, q2, 0, 0, 0);
+      q3 = __builtin_amdgcn_mfma_f32_4x4x4f16(c4, c4, q3, 0, 0, 0);
+    }
+    if constexpr (V == 9) {
+      acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, 0.5f, acc4, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, 0.25f, q1, 0, 0, 0);
+      q2 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, 0.125f, q2, 0, 0, 0);
+      q3 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, 0.75f, q3, 0, 0, 0);
+    }
+    if constexpr (V == 10) {
+      acc4 = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, c4, acc4, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f32_16x16x16f16(c4, a4, q1, 0, 0, 0);
+      q2 = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, a4, q2, 0, 0, 0);
+      q3 = __builtin_amdgcn_mfma_f32_16x16x16f16(c4, c4, q3, 0, 0, 0);
+    }
   }
+  for (int e = 0; e < 4; ++e) acc4[e] += q1[e] + q2[e] + q3[e];
   float s = acc4[0] + acc4[1] + acc4[2] + acc4[3];
   for (int e = 0; e < 16; ++e) s += acc[e];
   if (s == 12345.678f) sink[0] = s;  // keep the loop
@@ -45,6 +71,10 @@ extern "C" int mfma_burn(int variant, float* sink, int blocks, int iters, void* 
     case 4: hipLaunchKernelGGL(burn<4>, dim3(blocks), dim3(256), 0, s, sink, iters); break;
     case 5: hipLaunchKernelGGL(burn<5>, dim3(blocks), dim3(256), 0, s, sink, iters); break;
     case 6: hipLaunchKernelGGL(burn<6>, dim3(blocks), dim3(256), 0, s, sink, iters); break;
+    case 7: hipLaunchKernelGGL(burn<7>, dim3(blocks), dim3(256), 0, s, sink, iters); break;
+    case 8: hipLaunchKernelGGL(burn<8>, dim3(blocks), dim3(256), 0, s, sink, iters); break;
+    case 9: hipLaunchKernelGGL(burn<9>, dim3(blocks), dim3(256), 0, s, sink, iters); break;
+    case 10: hipLaunchKernelGGL(burn<10>, dim3(blocks), dim3(256), 0, s, sink, iters); break;
     default: return 1;
   }
   return (int)hipGetLastError();

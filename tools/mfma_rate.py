@@ -15,7 +15,10 @@ subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared"
 lib = ctypes.CDLL(out)
 sink = torch.zeros(16, device="cuda")
 NAMES = {0: ("32x32x16_f16", 2 * 32 * 32 * 16), 1: ("16x16x32_f16", 2 * 16 * 16 * 32), 4: ("32x32x8_f16", 2 * 32 * 32 * 8),
-         6: ("16x16x16_f16", 2 * 16 * 16 * 16), 5: ("32x32x2_f32", 2 * 32 * 32 * 2)}
+         6: ("16x16x16_f16", 2 * 16 * 16 * 16), 5: ("32x32x2_f32", 2 * 32 * 32 * 2),
+         # four independent accumulators per loop trip (flop per trip = 4 instructions)
+         7: ("4 x 4x4x1_f32", 4 * 2 * 16 * 4 * 4 * 1), 8: ("4 x 4x4x4_f16", 4 * 2 * 16 * 4 * 4 * 4), 9: ("4 x 16x16x4_f32", 4 * 2 * 16 * 16 * 4),
+         10: ("4 x 16x16x16_f16", 4 * 2 * 16 * 16 * 16)}
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for v, (name, flop) in NAMES.items():
     for blocks in (256, 1024):   # one / four waves per SIMD
