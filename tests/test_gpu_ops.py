@@ -740,3 +740,62 @@ def test_bank_cache_one_workgroup_per_stream_equals_the_serial_walk(bs, threshol
         for k in ("conf", "cf", "ca", "iid", "prev"):
             assert torch.equal(states[0][k], states[1][k]), (step, k)
         assert int(states[1]["prev"]) > 0 and int(sync[1]) == step + 1 and int(sync[0]) == (step + 1) * bs
+
+
+def test_bank_cache_per_stream_writes_nothing_while_a_hold_flag_is_set():
+    """The frame-end commit holds back when an overflow flag (or the sticky word of the frame before) is set -- the frame is
+    going to be re-run on the state it found (runner.py). The per-stream kernel must then leave the state, prev_id AND its
+    own meeting counters untouched (every workgroup returns in front of the meeting), and commit normally afterwards."""
+    from simpb_amd import _lib
+    from simpb_amd.plugin.ops import _ptr, _stream
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(7)
+    bs, A, T, C, E = 4, 900, 600, 10, 256
+    st = dict(conf=torch.rand(bs, T, generator=g).cuda(), cf=torch.randn(bs, T, E, generator=g).cuda(), ca=torch.randn(bs, T, 11, generator=g).cuda(),
+              iid=torch.randint(-1, 50, (bs, A), generator=g).cuda(), prev=torch.tensor(1234).cuda())
+    before = {k: v.clone() for k, v in st.items()}
+    sync = torch.zeros(2, dtype=torch.int32, device="cuda")
+    feat, anchor = torch.randn(bs, A, E, generator=g).cuda(), torch.randn(bs, A, 11, generator=g).cuda()
+    cls = torch.randn(bs, A, C, generator=g).cuda()
+    ids_out = torch.full((bs, A), -7, dtype=torch.long, device="cuda")
+    scratch = torch.empty(bs, T, dtype=torch.int32, device="cuda")
+    sticky = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def commit(hold):
+        _lib.check(lib.simpb_bank_cache_streams(
+            _ptr(st["conf"]), _ptr(st["cf"]), _ptr(st["ca"]), _ptr(st["iid"]), _ptr(st["prev"]), _ptr(ids_out), _ptr(scratch),
+            _ptr(feat), _ptr(anchor), _ptr(cls), bs, A, C, T, E, 1, 0.6, 0, 0.0, _ptr(hold), hold.numel(), _ptr(sticky), _ptr(sync),
+            _stream()), "bank_cache")
+        torch.cuda.synchronize()
+
+    commit(torch.tensor([0, 1, 0], dtype=torch.int32, device="cuda"))
+    for k in st:
+        assert torch.equal(st[k], before[k]), k
+    assert int(sticky) == 1 and sync.tolist() == [0, 0] and bool((ids_out == -7).all())
+    sticky.zero_()
+    commit(torch.zeros(3, dtype=torch.int32, device="cuda"))
+    assert int(sticky) == 0 and sync.tolist() == [bs, 1] and int(st["prev"]) > 1234 and not torch.equal(st["conf"], before["conf"])
+    assert bool((ids_out >= 0).all())   # no threshold: every instance has an id after a commit
+
+
+@pytest.mark.parametrize("rows_in,rows_out,kept", [(1536, 1800, 377), (700, 64, 0), (300, 64, 64), (2304, 96, 130)])
+def test_record2d_compact_vs_torch(rows_in, rows_out, kept):
+    """csrc/decode.hip record2d_compact_kernel (the exchange's 2D payload) against the torch statement of the same
+    compaction (simpb_amd.dist.compact_record2d on CPU tensors): kept rows in slot order, pad rows behind; no kept rows at
+    all; exactly full; more kept rows than the output holds (clipped); a strided output (streams of a wider send buffer)."""
+    from simpb_amd.dist import compact_record2d
+    g = torch.Generator().manual_seed(rows_in + kept)
+    bs = 3
+    rec = torch.rand(bs, rows_in, 8, generator=g)
+    rec[..., 6:8] = -1.0
+    for b in range(bs):
+        idx = torch.randperm(rows_in, generator=g)[:kept]
+        rec[b, idx, 6] = torch.randint(0, 300, (kept,), generator=g).float()
+        rec[b, idx, 7] = torch.randint(0, 6, (kept,), generator=g).float()
+        rec[b, torch.randperm(rows_in, generator=g)[:50], 7] = 2.0   # a camera but no kept box: not sent
+    want = compact_record2d(rec.clone(), rows_out)
+    got = compact_record2d(rec.cuda(), rows_out).cpu()
+    assert torch.equal(got, want)
+    wide = torch.full((bs, 40 + rows_out * 8), 9.0, device="cuda")   # the exchange's send buffer: 3D part in front
+    compact_record2d(rec.cuda(), rows_out, out=wide[:, 40:].unflatten(1, (rows_out, 8)))
+    assert torch.equal(wide[:, 40:].cpu().reshape(bs, rows_out, 8), want) and bool((wide[:, :40] == 9.0).all())
