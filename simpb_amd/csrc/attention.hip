@@ -19,7 +19,6 @@
 // tile is directly the B operand of O^T += V^T.P^T (k-order of the second product follows the
 // accumulator's row map), leaving O^T with the query on the lane again for the rescale.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include "../../include/simpb_hip.h"
 
 extern "C" int simpb_check_launch(void);
@@ -232,7 +231,7 @@ __device__ __forceinline__ void unpack4(const float* w, h16x4& hi, h16x4& lo) {
   lo = __builtin_bit_cast(h16x4, l);
 }
 
-template <bool GROUPED, bool PACKED>
+template <bool GROUPED, bool PACKED = false>
 __global__ __launch_bounds__(kWaves * 64) void attention_f16s_kernel(
     float* __restrict__ out, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const int* __restrict__ query_cam, const int* __restrict__ group_start, int Nq, int Nk, int ldq, int ldk, int ldv,
@@ -652,23 +651,11 @@ static int attention_launch(int split, float* out, const float* q, const float* 
   else if (split == 2)
     hipLaunchKernelGGL((attention_halfs_kernel<false, 8>), grid, dim3(512), 0, s, out, q, k, v, query_cam, group_start, num_query,
                        num_key, ldq, ldk, ldv, ldo);
-  else if (split == 3 && query_cam)   // (measurement forms: four waves; the first packed kernel)
-    hipLaunchKernelGGL((attention_halfs_kernel<true, 4>), grid, block, 0, s, out, q, k, v, query_cam, group_start, num_query,
-                       num_key, ldq, ldk, ldv, ldo);
-  else if (split == 3)
-    hipLaunchKernelGGL((attention_halfs_kernel<false, 4>), grid, block, 0, s, out, q, k, v, query_cam, group_start, num_query,
-                       num_key, ldq, ldk, ldv, ldo);
-  else if (split == 4 && query_cam)
-    hipLaunchKernelGGL((attention_f16s_kernel<true, true>), grid, block, 0, s, out, q, k, v, query_cam, group_start, num_query,
-                       num_key, ldq, ldk, ldv, ldo, scale);
-  else if (split == 4)
-    hipLaunchKernelGGL((attention_f16s_kernel<false, true>), grid, block, 0, s, out, q, k, v, query_cam, group_start, num_query,
-                       num_key, ldq, ldk, ldv, ldo, scale);
   else if (split && query_cam)
-    hipLaunchKernelGGL((attention_f16s_kernel<true, false>), grid, block, 0, s, out, q, k, v, query_cam, group_start, num_query,
+    hipLaunchKernelGGL((attention_f16s_kernel<true>), grid, block, 0, s, out, q, k, v, query_cam, group_start, num_query,
                        num_key, ldq, ldk, ldv, ldo, scale);
   else if (split)
-    hipLaunchKernelGGL((attention_f16s_kernel<false, false>), grid, block, 0, s, out, q, k, v, query_cam, group_start, num_query,
+    hipLaunchKernelGGL((attention_f16s_kernel<false>), grid, block, 0, s, out, q, k, v, query_cam, group_start, num_query,
                        num_key, ldq, ldk, ldv, ldo, scale);
   else if (query_cam)
     hipLaunchKernelGGL(attention_f32_kernel<true>, grid, block, 0, s, out, q, k, v, query_cam, group_start, num_query,
@@ -696,8 +683,7 @@ extern "C" int simpb_attention_f32_split(float* out, const float* q, const float
 extern "C" int simpb_attention_split_halfs(float* out, const void* q, const void* k, const void* v, const int* query_cam,
                                            const int* group_start, int batch_size, int num_heads, int head_dim, int num_query,
                                            int num_key, int ldq, int ldk, int ldv, int ldo, void* stream) {
-  static const int form = getenv("SIMPB_ATTENTION_FORM") ? atoi(getenv("SIMPB_ATTENTION_FORM")) : 2;   // measurement only: 3, 4
-  return attention_launch(form >= 2 && form <= 4 ? form : 2, out, static_cast<const float*>(q), static_cast<const float*>(k),
-                          static_cast<const float*>(v), query_cam, group_start, batch_size, num_heads, head_dim, num_query,
-                          num_key, ldq, ldk, ldv, ldo, 1.f, stream);
+  return attention_launch(2, out, static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v),
+                          query_cam, group_start, batch_size, num_heads, head_dim, num_query, num_key, ldq, ldk, ldv, ldo, 1.f,
+                          stream);
 }

@@ -28,7 +28,6 @@
 //  * Workgroups are numbered so that each XCD (blockIdx % 8) walks a contiguous range of tiles:
 //    neighbouring tiles share their X rows in that XCD's L2.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include <type_traits>
 #include "../../include/simpb_hip.h"
 #include "mfma_f16.h"
@@ -661,8 +660,8 @@ extern "C" int simpb_gemm_f32(const simpb_gemm_args* args, void* stream) {
   long long tiles_wide = 0;
   for (int j = 0; j < args->num_jobs; ++j)
     tiles_wide += (long long)((args->job[j].M + kWM - 1) / kWM) * ((args->job[j].N + kWN - 1) / kWN);
-  static const long long wide_min = getenv("SIMPB_GEMM_WIDE_MIN_TILES") ? atoll(getenv("SIMPB_GEMM_WIDE_MIN_TILES")) : 400;   // (env: measurement only)
-  const bool wide_tiles = split && tiles_wide >= wide_min;
+  constexpr long long kWideMinTiles = 400;
+  const bool wide_tiles = split && tiles_wide >= kWideMinTiles;
   long long total = 0;
   for (int j = 0; j < args->num_jobs; ++j) {
     L.tile_start[j] = (int)total;

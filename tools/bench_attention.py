@@ -54,7 +54,6 @@ def main():
     pre, post = nn.Linear(256, 512, bias=False).cuda(), nn.Linear(512, 256, bias=False).cuda()
     f, p = torch.randn(1, 900, 256, device="cuda"), torch.randn(1, 900, 256, device="cuda")
     tf, tp = torch.randn(1, 600, 256, device="cuda"), torch.randn(1, 600, 256, device="cuda")
-    print("attention form (SIMPB_ATTENTION_FORM: 2 = eight waves, 3 = four waves, 4 = first packed kernel):", os.environ.get("SIMPB_ATTENTION_FORM", "2"))
     with torch.no_grad():
         for name, (query, key, value, kp) in [("gnn block", (f, None, f, None)), ("temp_gnn block", (f, tf, tf, tp))]:
             line = []

@@ -1,5 +1,5 @@
 """Per-key-tile cost of the packed-operand attention kernels: 900 queries against 900 / 1800 / 3600 / 7200 keys (the fixed
-costs -- launch, Q, the meeting of the waves -- cancel in the differences). SIMPB_ATTENTION_FORM selects the kernel."""
+costs -- launch, Q, the meeting of the waves -- cancel in the differences)."""
 import os
 import sys
 
@@ -25,7 +25,7 @@ for nk in (900, 1800, 3600, 7200):
     line = [f"Nk {nk}:"]
     t_exact = timed(lambda: ops.attention_f32(buf[:, :900, :512], buf[:, :, 512:1024], buf[:, :, 1024:], 8, split=0), 100)
     t_pack = timed(lambda: ops.attention_f32(p[:, :900, :512], p[:, :, 512:1024], p[:, :, 1024:], 8, split=2), 100)
-    line.append(f"exact fp32 {t_exact:.1f} us, packed halfs (form {os.environ.get('SIMPB_ATTENTION_FORM', '2')}) {t_pack:.1f} us")
+    line.append(f"exact fp32 {t_exact:.1f} us, pre-split halfs, eight waves {t_pack:.1f} us")
     if prev is not None:
         dt = (nk - prev[0]) / 32
         line.append(f"per 32-key tile step of all workgroups: exact {(t_exact - prev[1]) / dt * 1e3:.0f} ns, packed {(t_pack - prev[2]) / dt * 1e3:.0f} ns")

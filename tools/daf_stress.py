@@ -60,7 +60,7 @@ def main():
     if args.victim != "daf":
         # the decoder's dense kernels whose files are NOT built with NO_PACKED_FP32 (simpb_amd/build.py): row statistics of the
         # LayerNorm (csrc/gemm.hip), the softmax of the attention kernels, the chain kernel's LayerNorm / post stages, the GEMM epilogue
-        from simpb_amd.plugin import dense, fused
+        from simpb_amd.plugin import dense
         victim_x = torch.randn(1, 900, 512, generator=g).cuda()   # (its own name: `vx` below is a co-runner operand)
         if args.victim == "layernorm":
             ln = torch.nn.LayerNorm(512).cuda()
