@@ -415,8 +415,11 @@ __global__ __launch_bounds__(kWaves * 64) void attention_f16s_kernel(
 // arguments, no masks / clamps on full tiles (workgroup-uniform branch), accumulators rescaled only when some lane's
 // running maximum moved. The eight partial results meet in two steps (waves 4-7 hand theirs to waves 0-3 through LDS,
 // then the four-way meeting of the kernels above), so LDS stays at 35 KB.
+// (launch bounds: at least 8 waves per CU in either form, i.e. at most 256 registers per wave. The four-wave form -- used for the
+// camera-grouped launches, whose ~190-key groups are 6 key tiles: nothing for eight waves to split -- then fits two workgroups
+// per CU, and the 280 live workgroups of a 1 130-slot 2D set run as ONE round of the chip instead of 256 + 24.)
 template <bool GROUPED, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void attention_halfs_kernel(
+__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void attention_halfs_kernel(
     float* __restrict__ out, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const int* __restrict__ query_cam, const int* __restrict__ group_start, int Nq, int Nk, int ldq, int ldk, int ldv,
     int ldo) {
@@ -646,7 +649,7 @@ static int attention_launch(int split, float* out, const float* q, const float* 
   dim3 grid((num_query + 31) / 32, num_heads, batch_size), block(kWaves * 64);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (split == 2 && query_cam)
-    hipLaunchKernelGGL((attention_halfs_kernel<true, 8>), grid, dim3(512), 0, s, out, q, k, v, query_cam, group_start, num_query,
+    hipLaunchKernelGGL((attention_halfs_kernel<true, 4>), grid, dim3(256), 0, s, out, q, k, v, query_cam, group_start, num_query,
                        num_key, ldq, ldk, ldv, ldo);
   else if (split == 2)
     hipLaunchKernelGGL((attention_halfs_kernel<false, 8>), grid, dim3(512), 0, s, out, q, k, v, query_cam, group_start, num_query,
