@@ -701,3 +701,59 @@ def rows_match_t(a, b, tol):
         x = x.double()
         return torch.cat([x[:, :6], x[:, 6:7].sin(), x[:, 6:7].cos(), x[:, 7:]], dim=1).numpy()
     return rows_match(wrap(a), wrap(b), tol)
+
+
+def test_replayed_frames_of_the_bench_configuration_vs_oracle():
+    """What bench.py times, against the oracle: the shipped R50 704x256 configuration -- real fp16 ResNet50 + FPN writing the
+    token rows (fp32 + the f16 copy the 2D sampler gathers), the decoder as a replayed hipGraph (split-operand GEMMs and
+    attention, fused 3D aggregation, TOK = _Float16 2D sampler, chains, bank / decode kernels) -- frame by frame FROM THE SAME
+    STATE: before a replayed frame the bank state is copied out, the frame's tokens are recorded, and OracleHead (CPU, fp32)
+    runs the same frame from that state on those tokens. Every detection (3D boxes / scores / labels, 2D boxes, the 2D<->3D
+    association, ids up to relabelling: tests.helpers.compare_result, 1e-3) and the bank state the frame leaves (kept rows
+    as sets) must agree. Whole-stream comparisons drift (profiles/r04_ragged_cause.md), same-state frames must not."""
+    from oracle import simpb_ref as R
+    from simpb_amd import configs, plugin
+    from simpb_amd.runner import FrameRunner
+    from tests.test_gpu_head import _oracle_result_as_golden
+    wh = (704, 256)
+    cfg = configs.simpb_plus(anchor=synth.anchors(900))
+    model = plugin.build_detector(cfg["model"]).eval()
+    synth.load_procedural(model)
+    model = model.cuda().fuse_conv_bn().half_backbone()
+    runner = FrameRunner(model, 1, (wh[1], wh[0]), capacity=1536, device=torch.device("cuda"), use_graph=True)
+    head = runner.head
+    params = {k: v.detach().cpu() for k, v in head.state_dict().items()}
+    bank = head.instance_bank
+    torch.set_num_threads(16)
+    frames, checked = 6, 0
+    prev = None
+    for f in range(frames):
+        metas = synth.frame_metas(1, f, wh)
+        img = synth.images(1, f % 4, wh).cuda()
+        torch.cuda.synchronize()
+        state = {k: v.clone().cpu() for k, v in bank._static.items()}
+        got = runner.step(img, metas)[0]["img_bbox"]
+        if f >= 3:   # replayed frames (the graph is captured at the second warm frame)
+            assert runner.stats["replay"] >= 1
+            with torch.no_grad():
+                fm = model.extract_feat(img)   # deterministic kernels: the tokens the replayed frame computed from this image
+                col = fm[0].float().cpu()
+                assert getattr(fm[0], "simpb_f16", None) is not None and torch.equal(fm[0].simpb_f16.float().cpu(), col)
+                oracle = R.OracleHead(params, head.operation_order)
+                ob = oracle.bank
+                ob.cached_feature, ob.cached_anchor = state["cached_feature"].clone(), state["cached_anchor"].clone()
+                ob.confidence, ob.instance_id = state["confidence"].clone(), state["instance_id"].clone()
+                ob.prev_id = int(state["prev_id"])
+                ob.metas = dict(timestamp=prev["timestamp"], img_metas=prev["img_metas"])
+                want = oracle.forward([col, fm[1].cpu(), fm[2].cpu()], metas)
+                res = oracle.post_process(want, metas)[0]
+            compare_result(got, _oracle_result_as_golden(res, "w."), "w.")
+            torch.cuda.synchronize()
+            for name, w_ in (("cached_feature", ob.cached_feature[0]), ("cached_anchor", ob.cached_anchor[0])):
+                a = bank._static[name][0].cpu()
+                d = torch.cdist(a.double(), w_.double(), p=float("inf"))
+                assert float(torch.maximum(d.min(dim=1).values, d.min(dim=0).values).max()) <= 1e-3, (f, name)
+            assert float((torch.sort(bank._static["confidence"][0].cpu()).values - torch.sort(ob.confidence[0]).values).abs().max()) <= 1e-3
+            checked += 1
+        prev = metas
+    assert checked == 3 and runner.stats["overflow"] == 0
